@@ -1,0 +1,380 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle: unidirectional path tracer with NEE.
+//
+// Restates the per-sample loop of the reference's CUDA kernel
+// (reference: src/pt_cu.cu:20-250, cuda_path_trace_kernel) on the CPU, with the
+// reference's brute-force scene scans (include/geometric.cuh:293-388).  It is the
+// checker for the HIP kernels; nothing in path_tracing_amd/ links or calls it.
+//
+// PARITY STATUS: parity unpinned (see ref_math.hpp header and tests/golden/README.md).
+//
+// Behaviour the reference leaves undefined, defined here exactly as in DESIGN.md:
+//  * shadow rays (check_visibility reads uninitialised mtl_old, geometric.cuh:310-311,
+//    319-320): a blocker is opaque iff its mtl.eta <= 0, otherwise its
+//    transmittance is 1 (what src/cpu_bdpt.cpp:102 does).  opts.glass_shadow_opaque=1
+//    makes every blocker opaque (the "zeroed mtl_old" reading).
+//  * delta bounces are free and uncapped (pt_cu.cu:228): capped at opts.max_delta.
+//  * bsdf_sample's total-internal-reflection return (geometric.cuh:514) ends the path.
+//  * the three bsdf_sample uniforms are drawn in the order u_rr, u1, u2 (pt_cu.cu:210-212).
+//  * uniforms are in [0,1) (cuRAND's are in (0,1]; the stream is unseeded there anyway).
+#include "ref_math.hpp"
+#include <algorithm>
+#include <random>
+#include <vector>
+#include <omp.h>
+
+using namespace orc;
+
+extern "C" {
+
+struct OraclePtOpts {
+    uint64_t seed;          // counter mode: stream key; mt mode: per-pixel seed base (seed + pixel index)
+    int rng_mode;           // 0 = PCG counter streams (GPU-compatible), 1 = std::mt19937 per pixel
+    int trig_mode;          // 0 = shared polynomial sincos, 1 = glibc sinf/cosf
+    int sample_offset;      // first global sample index (counter mode)
+    int x0, y0, x1, y1;     // render window [x0,x1) x [y0,y1) inside the W x H image
+    int threads;            // OpenMP threads (0 = default)
+    int glass_shadow_opaque;
+    int max_delta;          // cap on free delta bounces per sample
+    int output_sum;         // 1: write the per-pixel sum over samples instead of the mean
+    int ball_draw_reversed; // 1: the three uniforms of a unit-ball try fill z,y,x (argument evaluation
+                            //    order of make_float3(u(),u(),u()) is unspecified, geometric.cuh:410)
+};
+
+struct OraclePtStats {
+    uint64_t samples, closest_rays, shadow_rays, bounces, delta_bounces, tri_tests, sphere_tests;
+};
+
+} // extern "C"
+
+namespace {
+
+struct Rng {
+    int mode;
+    Pcg pcg;
+    std::mt19937 mt;
+    std::uniform_real_distribution<float> U{0.0f, 1.0f};
+    float next(){ return mode == 0 ? pcg.next() : U(mt); }
+};
+
+struct Scene {
+    const RLight *lights; int nl;
+    const RSphere *spheres; int ns;
+    const RTriangle *tris; int nt;
+    std::vector<float> cos_cutoff;     // cosf(light.cutoff), hoisted (pt_cu.cu:73,79,168)
+};
+
+// geometric.cuh:327-388 -- spheres, then light balls, then triangles; strict '<'
+Hit closest_hit(const Scene &sc, V3 ro, V3 rd, OraclePtStats &st){
+    Hit best; best.hit = false; best.t = 1e20f; best.is_light = false; best.prim = -1;
+    best.mtl.base_color = v3(0, 0, 0); best.mtl.roughness = 0; best.mtl.metallic = 0; best.mtl.eta = 0; best.mtl.type = 0;
+    best.pos = v3(0, 0, 0); best.normal = v3(0, 0, 0);
+    float t; const float max_dist = 1e20f;
+    st.sphere_tests += (uint64_t) (sc.ns + sc.nl);
+    st.tri_tests += (uint64_t) sc.nt;
+    for(int i = 0; i < sc.ns; ++i){
+        const RSphere &s = sc.spheres[i];
+        if(intersect_sphere(ro, rd, s.center, s.r, t, max_dist) && t < best.t){
+            best.hit = true; best.t = t; best.mtl = s.mtl;
+            best.pos = ro + rd * t;
+            best.normal = normalize(best.pos - s.center);
+            best.is_light = false; best.prim = i;
+            if(dot(best.normal, rd) > 0.0f) best.normal = best.normal * -1.0f;
+        }
+    }
+    for(int i = 0; i < sc.nl; ++i){
+        const RSphere &s = sc.lights[i].light_ball;
+        if(intersect_sphere(ro, rd, s.center, s.r, t, max_dist) && t < best.t){
+            best.hit = true; best.t = t;
+            best.mtl.base_color = sc.lights[i].illum;          // only field set (geometric.cuh:360-361)
+            best.pos = ro + rd * t;
+            best.normal = normalize(best.pos - s.center);
+            best.is_light = true; best.prim = sc.ns + i;
+            if(dot(best.normal, rd) > 0.0f) best.normal = best.normal * -1.0f;
+        }
+    }
+    for(int i = 0; i < sc.nt; ++i){
+        const RTriangle &tr = sc.tris[i];
+        if(intersect_triangle(ro, rd, tr.v0, tr.v1, tr.v2, t, max_dist) && t < best.t){
+            best.hit = true; best.t = t; best.mtl = tr.mtl;
+            best.pos = ro + rd * t;
+            best.normal = normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0));
+            best.is_light = false; best.prim = sc.ns + sc.nl + i;
+            if(dot(best.normal, rd) > 0.0f) best.normal = best.normal * -1.0f;
+        }
+    }
+    return best;
+}
+
+// geometric.cuh:293-325 -- triangles then spheres (not light balls); range (1e-3, dist-1e-3)
+bool visible(const Scene &sc, V3 p1, V3 p2, bool glass_opaque, OraclePtStats &st){
+    V3 diff = p2 - p1;
+    float dist = length(diff);
+    V3 dir = diff / dist;
+    float max_d = dist - 1e-3f;
+    const float min_d = 1e-3f;
+    float t;
+    st.tri_tests += (uint64_t) sc.nt;
+    st.sphere_tests += (uint64_t) sc.ns;
+    for(int i = 0; i < sc.nt; ++i){
+        const RTriangle &tr = sc.tris[i];
+        if(intersect_triangle(p1, dir, tr.v0, tr.v1, tr.v2, t, max_d) && t > min_d){
+            if(glass_opaque || tr.mtl.eta <= 0.0f) return false;
+        }
+    }
+    for(int i = 0; i < sc.ns; ++i){
+        const RSphere &s = sc.spheres[i];
+        if(intersect_sphere(p1, dir, s.center, s.r, t, max_d) && t > min_d){
+            if(glass_opaque || s.mtl.eta <= 0.0f) return false;
+        }
+    }
+    return true;
+}
+
+// geometric.cuh:407-413
+V3 random_in_unit_sphere(Rng &rng, bool reversed){
+    V3 p;
+    do {
+        float a = rng.next(), b = rng.next(), c = rng.next();
+        p = (reversed ? v3(c, b, a) : v3(a, b, c)) * 2.0f - v3(1.0f, 1.0f, 1.0f);
+    } while(dot(p, p) >= 1.0f);
+    return p;
+}
+
+// one camera sample, pt_cu.cu:36-245
+V3 trace_sample(const Scene &sc, const RCamera &cam, int px, int py, int max_depth,
+                const OraclePtOpts &o, Rng &rng, OraclePtStats &st){
+    V3 final_color = v3(0, 0, 0);
+    float pixel_x = (float) px + rng.next();
+    float pixel_y = (float) py + rng.next();
+    V3 ray_o = cam.eye;
+    V3 pixel_pos = cam.UL + cam.dx * pixel_x + cam.dy * pixel_y;
+    V3 ray_d = normalize(pixel_pos - ray_o);
+    float ray_eta = 1.0f;
+    V3 throughput = v3(1.0f, 1.0f, 1.0f);
+    bool last_is_delta = true;
+    int delta_count = 0;
+    st.samples++;
+
+    for(int depth = 0; depth < max_depth; ++depth){
+        Hit hit = closest_hit(sc, ray_o, ray_d, st);
+        st.closest_rays++;
+        if(!hit.hit) break;
+        V3 wo = ray_d * -1.0f;
+
+        if(hit.is_light){                                   // pt_cu.cu:59-122
+            V3 emission = hit.mtl.base_color;
+            float area = 1.0f, cone_ratio = 1.0f;
+            bool valid_light = false;
+            for(int i = 0; i < sc.nl; ++i){
+                const RLight &L = sc.lights[i];
+                V3 c2h = hit.pos - L.pos;
+                if(fabsf(length(c2h) - L.light_ball.r) < 1e-2f){
+                    valid_light = true;
+                    area = 4.0f * kPi * L.light_ball.r * L.light_ball.r;
+                    if(L.cutoff > 0.0f && !L.is_parallel){
+                        cone_ratio = (1.0f - sc.cos_cutoff[i]) / 2.0f;
+                        V3 main_dir = normalize(L.dir);
+                        if(depth == 0) cone_ratio = 1.f;
+                        else if(dot(main_dir, normalize(c2h)) < sc.cos_cutoff[i]) cone_ratio = 0.0f;
+                    }
+                    break;
+                }
+            }
+            if(valid_light && cone_ratio > 0.0f) emission = emission / (area * cone_ratio);
+            else emission = v3(0, 0, 0);
+            if(emission.x > 0.0f || emission.y > 0.0f || emission.z > 0.0f){
+                if(last_is_delta){
+                    V3 contrib = throughput * emission;
+                    if(is_valid_color(contrib)) final_color = final_color + clamp_radiance(contrib, 15.0f);
+                }
+                // else: the reference's MIS branch is a stub with pdf_light_dir = 0 (pt_cu.cu:103-118)
+            }
+            break;
+        }
+
+        // next-event estimation, pt_cu.cu:125-202
+        if(hit.mtl.eta <= 0.0f && (hit.mtl.metallic < 0.99f || hit.mtl.roughness > 0.01f) && sc.nl > 0){
+            int l_idx = std::min((int) (rng.next() * sc.nl), sc.nl - 1);
+            const RLight &light = sc.lights[l_idx];
+            if(light.is_parallel){
+                V3 light_dir = normalize(light.dir * -1.0f);
+                float cos_surface = fmaxf(0.0f, dot(hit.normal, light_dir));
+                if(cos_surface > 0.0f){
+                    st.shadow_rays++;
+                    if(visible(sc, hit.pos + hit.normal * kEps, hit.pos + light_dir * 1e4f, o.glass_shadow_opaque != 0, st)){
+                        V3 brdf = bsdf_evaluate(hit.mtl, wo, light_dir, hit.normal);
+                        V3 transmittance = v3(1.0f, 1.0f, 1.0f);
+                        V3 contrib = throughput * brdf * light.illum * transmittance * cos_surface * (float) sc.nl;
+                        if(is_valid_color(contrib)) final_color = final_color + clamp_radiance(contrib, 15.0f);
+                    }
+                }
+            } else {
+                V3 d_local = random_in_unit_sphere(rng, o.ball_draw_reversed != 0);
+                if(length(d_local) > 0.001f) d_local = normalize(d_local);
+                else d_local = v3(0, 1, 0);
+                V3 light_pos = light.pos + d_local * light.light_ball.r;
+                V3 wi_light = light_pos - hit.pos;
+                float dist2 = dot(wi_light, wi_light);
+                float dist = sqrtf(dist2);
+                wi_light = wi_light / dist;
+                float cos_surface = fmaxf(0.0f, dot(hit.normal, wi_light));
+                float cos_light = fmaxf(0.0f, dot(d_local, wi_light * -1.0f));
+                if(cos_surface > 0.0f && cos_light > 0.0f){
+                    bool inside_cone = true;
+                    if(light.cutoff > 0.0f && !light.is_parallel){
+                        V3 main_dir = normalize(light.dir);
+                        if(dot(main_dir, wi_light * -1.0f) < sc.cos_cutoff[l_idx]) inside_cone = false;
+                    }
+                    if(inside_cone){
+                        st.shadow_rays++;
+                        if(visible(sc, hit.pos + hit.normal * kEps, light_pos + d_local * kEps, o.glass_shadow_opaque != 0, st)){
+                            float area = 4.0f * kPi * light.light_ball.r * light.light_ball.r;
+                            float pdf_light_area = 1.0f / (sc.nl * area);
+                            float pdf_light_dir = pdf_light_area * dist2 / fmaxf(cos_light, 1e-6f);
+                            float pdf_bsdf = bsdf_pdf(hit.mtl, wo, wi_light, hit.normal);
+                            float p_l = pdf_light_dir * pdf_light_dir;
+                            float p_b = pdf_bsdf * pdf_bsdf;
+                            float mis_w = p_l / fmaxf(p_l + p_b, 1e-8f);
+                            V3 brdf = bsdf_evaluate(hit.mtl, wo, wi_light, hit.normal);
+                            V3 transmittance = v3(1.0f, 1.0f, 1.0f);
+                            V3 contrib = throughput * brdf * light.illum * transmittance * cos_surface / pdf_light_dir * mis_w;
+                            if(is_valid_color(contrib)) final_color = final_color + clamp_radiance(contrib, 15.0f);
+                        }
+                    }
+                }
+            }
+        }
+
+        // BSDF sampling, pt_cu.cu:204-241
+        V3 wi, bsdf_val; float pdf_omega, new_eta; bool is_delta;
+        float u_rr = rng.next(), u1 = rng.next(), u2 = rng.next();
+        bsdf_sample(o.trig_mode, hit.mtl, wo, hit.normal, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
+        if(pdf_omega <= 0.0f) break;        // non-delta: pt_cu.cu:214; delta: the TIR return (defined: terminate)
+        st.bounces++;
+        if(is_delta){
+            throughput = throughput * bsdf_val;
+            ray_d = wi;
+            ray_eta = new_eta;
+            if(dot(wi, hit.normal) < 0.0f) ray_o = hit.pos - hit.normal * kEps;
+            else ray_o = hit.pos + hit.normal * kEps;
+            last_is_delta = true;
+            if(!is_valid_color(throughput)) break;
+            st.delta_bounces++;
+            if(++delta_count > o.max_delta) break;
+            depth--;
+            continue;
+        }
+        float cos_wi = fabsf(dot(hit.normal, wi));
+        throughput = throughput * bsdf_val * cos_wi / pdf_omega;
+        if(!is_valid_color(throughput)) break;
+        ray_d = wi;
+        ray_o = hit.pos + hit.normal * kEps;
+        last_is_delta = false;
+    }
+    if(!is_valid_color(final_color)) final_color = v3(0, 0, 0);
+    return final_color;
+}
+
+} // namespace
+
+extern "C" {
+
+// Renders the window [x0,x1)x[y0,y1) of a W x H image; pixels outside are left untouched.
+// Arguments mirror pt_render_wrapper (reference: include/pt_cu.cuh:6-13).
+int oracle_pt_render(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                     const void *camera, float *image, int W, int H, int max_depth, int spp,
+                     const OraclePtOpts *opts, OraclePtStats *stats_out){
+    if(!camera || !image || !opts || W <= 0 || H <= 0 || spp <= 0) return 1;
+    Scene sc;
+    sc.lights = (const RLight *) lights; sc.nl = nl;
+    sc.spheres = (const RSphere *) spheres; sc.ns = ns;
+    sc.tris = (const RTriangle *) tris; sc.nt = nt;
+    sc.cos_cutoff.resize(nl > 0 ? nl : 0);
+    for(int i = 0; i < nl; ++i) sc.cos_cutoff[i] = cosf(sc.lights[i].cutoff);
+    RCamera cam; memcpy(&cam, camera, sizeof cam);
+    OraclePtOpts o = *opts;
+    int x1 = o.x1 > 0 ? std::min(o.x1, W) : W, y1 = o.y1 > 0 ? std::min(o.y1, H) : H;
+    int x0 = std::max(o.x0, 0), y0 = std::max(o.y0, 0);
+    if(o.max_delta <= 0) o.max_delta = 64;
+    int nthreads = o.threads > 0 ? o.threads : omp_get_max_threads();
+    int ww = x1 - x0, wh = y1 - y0;
+    if(ww <= 0 || wh <= 0) return 1;
+    std::vector<OraclePtStats> tstats(nthreads);
+    for(auto &s : tstats) memset(&s, 0, sizeof s);
+
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+    for(int wi = 0; wi < ww * wh; ++wi){
+        int px = x0 + wi % ww, py = y0 + wi / ww;
+        int idx = py * W + px;
+        OraclePtStats &st = tstats[omp_get_thread_num()];
+        Rng rng; rng.mode = o.rng_mode;
+        if(o.rng_mode == 1) rng.mt.seed((uint32_t) (o.seed + (uint64_t) idx));
+        V3 color_sum = v3(0, 0, 0);
+        for(int s = 0; s < spp; ++s){
+            if(o.rng_mode == 0) rng.pcg.seed(o.seed, (uint32_t) idx, (uint32_t) (o.sample_offset + s));
+            V3 c = trace_sample(sc, cam, px, py, max_depth, o, rng, st);
+            color_sum = color_sum + c;                       // pt_cu.cu:245
+        }
+        V3 out = o.output_sum ? color_sum : color_sum / (float) spp;     // pt_cu.cu:248
+        image[3 * (size_t) idx + 0] = out.x;
+        image[3 * (size_t) idx + 1] = out.y;
+        image[3 * (size_t) idx + 2] = out.z;
+    }
+    if(stats_out){
+        OraclePtStats t; memset(&t, 0, sizeof t);
+        for(auto &s : tstats){
+            t.samples += s.samples; t.closest_rays += s.closest_rays; t.shadow_rays += s.shadow_rays;
+            t.bounces += s.bounces; t.delta_bounces += s.delta_bounces; t.tri_tests += s.tri_tests;
+            t.sphere_tests += s.sphere_tests;
+        }
+        *stats_out = t;
+    }
+    return 0;
+}
+
+// ---- function-level probes (known-answer style checks of the shared math) --------------
+void oracle_sincos_2pi(const float *u, int n, float *s, float *c){
+    for(int i = 0; i < n; ++i) sincos_2pi_poly(u[i], s[i], c[i]);
+}
+void oracle_pcg_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float *out){
+    Pcg p; p.seed(seed, pixel, sample);
+    for(int i = 0; i < n; ++i) out[i] = p.next();
+}
+// out[0..2] = f, out[3] = pdf   (geometric.cuh:419-484)
+void oracle_bsdf_eval_pdf(const float *mat7, const float *wo, const float *wi, const float *n, float *out){
+    RMat m; m.base_color = v3(mat7[0], mat7[1], mat7[2]); m.roughness = mat7[3]; m.metallic = mat7[4]; m.eta = mat7[5]; m.type = 0;
+    V3 f = bsdf_evaluate(m, v3(wo[0], wo[1], wo[2]), v3(wi[0], wi[1], wi[2]), v3(n[0], n[1], n[2]));
+    out[0] = f.x; out[1] = f.y; out[2] = f.z;
+    out[3] = bsdf_pdf(m, v3(wo[0], wo[1], wo[2]), v3(wi[0], wi[1], wi[2]), v3(n[0], n[1], n[2]));
+}
+// out[0..2] = wi, out[3..5] = f, out[6] = pdf, out[7] = is_delta, out[8] = new_eta   (geometric.cuh:486-562)
+void oracle_bsdf_sample(int trig_mode, const float *mat7, const float *wo, const float *n, const float *u3, float cur_eta, float *out){
+    RMat m; m.base_color = v3(mat7[0], mat7[1], mat7[2]); m.roughness = mat7[3]; m.metallic = mat7[4]; m.eta = mat7[5]; m.type = 0;
+    V3 wi, f; float pdf, ne; bool d;
+    bsdf_sample(trig_mode, m, v3(wo[0], wo[1], wo[2]), v3(n[0], n[1], n[2]), u3[0], u3[1], u3[2], cur_eta, wi, f, pdf, d, ne);
+    out[0] = wi.x; out[1] = wi.y; out[2] = wi.z; out[3] = f.x; out[4] = f.y; out[5] = f.z; out[6] = pdf; out[7] = d ? 1.0f : 0.0f; out[8] = ne;
+}
+// brute-force closest hit for a batch of rays: out t (1e20 = miss) and prim ordinal (-1 = miss)
+void oracle_closest_hits(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                         const float *ro, const float *rd, int nrays, float *t_out, int *prim_out){
+    Scene sc; sc.lights = (const RLight *) lights; sc.nl = nl; sc.spheres = (const RSphere *) spheres; sc.ns = ns;
+    sc.tris = (const RTriangle *) tris; sc.nt = nt;
+#pragma omp parallel for schedule(dynamic, 64)
+    for(int i = 0; i < nrays; ++i){
+        OraclePtStats st; memset(&st, 0, sizeof st);
+        Hit h = closest_hit(sc, v3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), v3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]), st);
+        t_out[i] = h.hit ? h.t : 1e20f; prim_out[i] = h.hit ? h.prim : -1;
+    }
+}
+void oracle_visibility(const void *spheres, int ns, const void *tris, int nt,
+                       const float *p1, const float *p2, int nrays, int glass_opaque, int *vis_out){
+    Scene sc; sc.lights = nullptr; sc.nl = 0; sc.spheres = (const RSphere *) spheres; sc.ns = ns;
+    sc.tris = (const RTriangle *) tris; sc.nt = nt;
+#pragma omp parallel for schedule(dynamic, 64)
+    for(int i = 0; i < nrays; ++i){
+        OraclePtStats st; memset(&st, 0, sizeof st);
+        vis_out[i] = visible(sc, v3(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]), v3(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]), glass_opaque != 0, st) ? 1 : 0;
+    }
+}
+
+} // extern "C"
