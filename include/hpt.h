@@ -1,0 +1,146 @@
+/* hpt.h -- C ABI of the MI355X-native path-tracing hot path (libhpt.so).
+ *
+ * Drop-in boundary for the reference renderer's unidirectional path-tracing launch
+ * API.  Every entry point takes plain pointers and sizes; the scene records are the
+ * reference's own host PODs, byte for byte:
+ *
+ *   light    144 B  reference include/geometric.cuh:73-78   (CudaLight)
+ *   sphere   100 B  reference include/geometric.cuh:29-35   (CudaSphere)
+ *   triangle 120 B  reference include/geometric.cuh:37-42   (CudaTriangle)
+ *   camera    84 B  reference include/geometric.cuh:67-69   (CudaCamera)
+ *   image    W*H*3 float32, row-major, row 0 = top, linear RGB mean radiance
+ *            (reference src/pt_cu.cu:30,248)
+ *
+ * What each entry point replaces in the reference:
+ *
+ *   hpt_pt_render_wrapper     pt_render_wrapper, include/pt_cu.cuh:6-13 (defined
+ *                             src/pt_cu.cu:255-297): alloc + upload + render + download
+ *                             in one blocking call.  include/hpt_reference_api.hpp
+ *                             declares the C++-linkage adapter of the same name.
+ *   hpt_scene_create/destroy  the per-call cudaMalloc/cudaMemcpy/cudaFree of the scene,
+ *                             src/pt_cu.cu:270-278,292-296, hoisted so a caller that
+ *                             renders repeatedly (reference src/main.cpp:416) uploads and
+ *                             builds the BVH once.
+ *   hpt_render_pt             cuda_path_trace_kernel launch + D2H, src/pt_cu.cu:282-290.
+ *   hpt_render_pt_device      same, leaving the result in device memory on a caller
+ *                             stream (no reference equivalent; used for multi-GPU tiling
+ *                             and for timing with inputs resident in HBM).
+ *
+ * All functions return 0 on success, non-zero on error; hpt_last_error() describes the
+ * last error of the calling thread.  Calls on one scene handle are not re-entrant.
+ */
+#ifndef HPT_H
+#define HPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPT_OK 0
+#define HPT_ERR_INVALID 1
+#define HPT_ERR_DEVICE 2
+#define HPT_ERR_NOMEM 3
+
+#define HPT_LIGHT_BYTES 144
+#define HPT_SPHERE_BYTES 100
+#define HPT_TRIANGLE_BYTES 120
+#define HPT_CAMERA_BYTES 84
+
+typedef struct hpt_scene hpt_scene;
+
+/* Render parameters that the reference fixes at compile time or leaves to the clock. */
+typedef struct hpt_params {
+    uint64_t seed;            /* RNG stream key (the reference seeds cuRAND from time(NULL), pt_cu.cu:282) */
+    int32_t sample_offset;    /* global index of this call's first sample (progressive rendering) */
+    int32_t max_delta;        /* cap on free delta bounces per sample (reference: uncapped, pt_cu.cu:228); 0 -> 64 */
+    int32_t rank;             /* image-tile partition: this device renders tiles t with t % world == rank */
+    int32_t world;            /* number of devices sharing the image; 0 or 1 -> whole image */
+    int32_t tile;             /* tile edge in pixels, multiple of 8; 0 -> 32 */
+    int32_t samples_per_pass; /* samples of every local pixel in flight at once; 0 -> auto */
+    int32_t flags;            /* HPT_FLAG_* */
+    int32_t reserved;
+} hpt_params;
+
+#define HPT_FLAG_BRUTE_FORCE 1   /* scan every primitive instead of the BVH (tests) */
+#define HPT_FLAG_COUNT_WORK 2    /* count BVH boxes/triangles tested (slower; fills hpt_stats) */
+#define HPT_FLAG_OUTPUT_SUM 4    /* leave the per-pixel sum over this call's samples, not the mean */
+#define HPT_FLAG_TIME_KERNELS 8  /* bracket every kernel launch with HIP events (fills hpt_stats.ms_*) */
+
+typedef struct hpt_stats {
+    uint64_t samples;         /* camera samples traced by the last render */
+    uint64_t closest_rays;    /* closest-hit rays */
+    uint64_t shadow_rays;     /* any-hit rays */
+    uint64_t boxes_tested;    /* child boxes slab-tested (2 per inner node visited); COUNT_WORK only */
+    uint64_t tris_tested;     /* triangle tests; COUNT_WORK only */
+    uint64_t path_iters;      /* (path, bounce) shading steps */
+    double ms_total;          /* device time first-to-last kernel of the last render (HIP events) */
+    double ms_extend, ms_shade, ms_connect, ms_other;   /* per-kernel-class sums; TIME_KERNELS only */
+    uint32_t n_extend, n_shade, n_connect, n_other;     /* launches per class */
+    uint32_t bvh_nodes, bvh_depth, n_tris, n_materials;
+    double ms_bvh_build, ms_upload;
+} hpt_stats;
+
+const char *hpt_last_error(void);
+
+/* Number of visible HIP devices (<0 on error). */
+int hpt_device_count(void);
+
+/* Flattens the reference records into the device layout, builds the BVH on the host and
+ * uploads everything to the current HIP device.  Records are copied; the caller keeps
+ * ownership of its arrays. */
+int hpt_scene_create(const void *lights, int num_lights,
+                     const void *spheres, int num_spheres,
+                     const void *triangles, int num_triangles,
+                     hpt_scene **out_scene);
+void hpt_scene_destroy(hpt_scene *scene);
+
+/* Number of float3 slots of the packed local framebuffer for this (W, H, params) -- the
+ * size hpt_render_pt_device writes and hpt_untile reads per rank. */
+int64_t hpt_local_pixels(int W, int H, const hpt_params *params);
+
+/* Blocking render into a caller-owned host image of W*H*3 floats (whole image:
+ * params->world must be 0 or 1). */
+int hpt_render_pt(hpt_scene *scene, const void *camera, int W, int H,
+                  int eye_depth, int spp, const hpt_params *params, float *host_image);
+
+/* Asynchronous render of this rank's tiles into device memory:
+ * d_local holds hpt_local_pixels() float3 records in local tile order. */
+int hpt_render_pt_device(hpt_scene *scene, const void *camera, int W, int H,
+                         int eye_depth, int spp, const hpt_params *params,
+                         void *d_local, void *hip_stream);
+
+/* Scatters `world` packed local framebuffers, laid out [rank][local pixel] in d_gathered,
+ * into the row-major W*H image d_image (both device pointers). */
+int hpt_untile(const void *d_gathered, void *d_image, int W, int H,
+               const hpt_params *params, void *hip_stream);
+
+/* One-shot equivalent of the reference's pt_render_wrapper (include/pt_cu.cuh:6-13):
+ * scene_min/scene_max/light_depth/light_sample are accepted and ignored there too
+ * (src/pt_cu.cu:259-262).  seed < 0 -> seed from the clock like the reference. */
+int hpt_pt_render_wrapper(const void *lights, int num_lights,
+                          const void *spheres, int num_spheres,
+                          const void *triangles, int num_triangles,
+                          const float scene_min[3], const float scene_max[3],
+                          const void *camera, float *host_image, int W, int H,
+                          int light_depth, int light_sample, int eye_depth, int spp,
+                          int64_t seed);
+
+int hpt_get_stats(const hpt_scene *scene, hpt_stats *out);
+
+/* Ray-level probes of the intersection kernels (tests): n rays, origins/directions as
+ * packed float3.  prim is the reference scan ordinal (spheres, then light balls, then
+ * triangles in input order), -1 on a miss; t is 1e20f on a miss. */
+int hpt_trace_closest(hpt_scene *scene, const float *origins, const float *dirs, int n,
+                      int flags, float *t_out, int32_t *prim_out);
+/* Shadow segments p1 -> p2 with the reference's (1e-3, dist-1e-3) range; visible_out[i] = 1
+ * when no opaque primitive blocks the segment. */
+int hpt_trace_visibility(hpt_scene *scene, const float *p1, const float *p2, int n,
+                         int flags, int32_t *visible_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPT_H */

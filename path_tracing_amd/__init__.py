@@ -1,0 +1,197 @@
+"""path_tracing_amd -- MI355X-native unidirectional path-tracing hot path.
+
+Python front-end of the C ABI in include/hpt.h (libhpt.so: hand-written HIP kernels for
+gfx950 + host BVH build).  Mirrors the reference's launch-and-accumulate helper API
+(reference include/pt_cu_helper.h:5-6, src/pt_cu_helper.cpp:12-77):
+
+    Scene(lights, spheres, triangles)      ~ move_data_to_cuda_pt (upload once)
+    Scene.render_pt(cam, W, H, depth, spp) ~ run_cuda_pt / pt_render_wrapper
+
+There is no CPU fallback: if libhpt.so is missing or no HIP device is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import layouts, scene_io  # noqa: F401
+from .layouts import CAMERA, LIGHT, SPHERE, TRIANGLE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhpt.so")
+
+FLAG_BRUTE_FORCE = 1
+FLAG_COUNT_WORK = 2
+FLAG_OUTPUT_SUM = 4
+FLAG_TIME_KERNELS = 8
+
+
+class HptError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("sample_offset", C.c_int32), ("max_delta", C.c_int32),
+                ("rank", C.c_int32), ("world", C.c_int32), ("tile", C.c_int32),
+                ("samples_per_pass", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("boxes_tested", C.c_uint64), ("tris_tested", C.c_uint64), ("path_iters", C.c_uint64),
+                ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_shade", C.c_double),
+                ("ms_connect", C.c_double), ("ms_other", C.c_double),
+                ("n_extend", C.c_uint32), ("n_shade", C.c_uint32), ("n_connect", C.c_uint32), ("n_other", C.c_uint32),
+                ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("n_tris", C.c_uint32), ("n_materials", C.c_uint32),
+                ("ms_bvh_build", C.c_double), ("ms_upload", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads csrc/libhpt.so; raises HptError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HptError("libhpt.so not built: run `make -C path_tracing_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        lib.hpt_last_error.restype = C.c_char_p
+        lib.hpt_local_pixels.restype = C.c_int64
+        lib.hpt_local_pixels.argtypes = [C.c_int, C.c_int, C.POINTER(Params)]
+        for name in ("hpt_scene_create", "hpt_render_pt", "hpt_render_pt_device", "hpt_untile",
+                     "hpt_pt_render_wrapper", "hpt_get_stats", "hpt_trace_closest", "hpt_trace_visibility",
+                     "hpt_device_count"):
+            getattr(lib, name).restype = C.c_int
+        lib.hpt_scene_destroy.restype = None
+        lib.hpt_scene_destroy.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise HptError("hpt error %d: %s" % (rc, load_library().hpt_last_error().decode("utf-8", "replace")))
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def device_count() -> int:
+    return int(load_library().hpt_device_count())
+
+
+def make_params(seed=1, sample_offset=0, max_delta=0, rank=0, world=1, tile=0, samples_per_pass=0, flags=0) -> Params:
+    p = Params()
+    p.seed, p.sample_offset, p.max_delta = int(seed), int(sample_offset), int(max_delta)
+    p.rank, p.world, p.tile, p.samples_per_pass, p.flags, p.reserved = rank, world, tile, samples_per_pass, flags, 0
+    return p
+
+
+def local_pixels(W: int, H: int, params: Params) -> int:
+    n = int(load_library().hpt_local_pixels(W, H, C.byref(params)))
+    if n < 0:
+        _check(1)
+    return n
+
+
+class Scene:
+    """Device-resident scene + BVH (the upload half of the reference's helper API:
+    move_data_to_cuda_pt, src/pt_cu_helper.cpp:12-64).  Inputs are arrays of the reference's
+    records (layouts.LIGHT / SPHERE / TRIANGLE), e.g. from scene_io.flatten_for_pt."""
+
+    def __init__(self, lights, spheres, triangles):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        lights = np.ascontiguousarray(lights, LIGHT)
+        spheres = np.ascontiguousarray(spheres, SPHERE)
+        triangles = np.ascontiguousarray(triangles, TRIANGLE)
+        _check(self._lib.hpt_scene_create(_vp(lights), len(lights), _vp(spheres), len(spheres),
+                                          _vp(triangles), len(triangles), C.byref(self._h)))
+        self.num_lights, self.num_spheres, self.num_triangles = len(lights), len(spheres), len(triangles)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.hpt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- rendering ----------------------------------------------------------------------
+    def render_pt(self, camera, W, H, eye_depth=4, spp=8, params: Params | None = None) -> np.ndarray:
+        """Blocking whole-image render (run_cuda_pt, src/pt_cu_helper.cpp:66-77).
+        Returns float32 [H, W, 3], row 0 = top, linear mean radiance."""
+        params = params or make_params()
+        cam = np.ascontiguousarray(camera, CAMERA)
+        img = np.empty((H, W, 3), np.float32)
+        _check(self._lib.hpt_render_pt(self._h, _vp(cam.reshape(1)), W, H, eye_depth, spp, C.byref(params), _vp(img)))
+        return img
+
+    def render_pt_device(self, camera, W, H, eye_depth, spp, params: Params, d_local_ptr: int, stream: int = 0):
+        """Asynchronous render of this rank's tiles into device memory (packed local order)."""
+        cam = np.ascontiguousarray(camera, CAMERA)
+        _check(self._lib.hpt_render_pt_device(self._h, _vp(cam.reshape(1)), W, H, eye_depth, spp, C.byref(params),
+                                              C.c_void_p(d_local_ptr), C.c_void_p(stream)))
+
+    def stats(self) -> dict:
+        st = Stats()
+        _check(self._lib.hpt_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    # -- ray probes (tests) ---------------------------------------------------------------
+    def trace_closest(self, origins, dirs, brute_force=False):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        n = len(o)
+        t = np.empty(n, np.float32)
+        prim = np.empty(n, np.int32)
+        _check(self._lib.hpt_trace_closest(self._h, _vp(o), _vp(d), n, FLAG_BRUTE_FORCE if brute_force else 0, _vp(t), _vp(prim)))
+        return t, prim
+
+    def trace_visibility(self, p1, p2, brute_force=False):
+        a = np.ascontiguousarray(p1, np.float32)
+        b = np.ascontiguousarray(p2, np.float32)
+        n = len(a)
+        vis = np.empty(n, np.int32)
+        _check(self._lib.hpt_trace_visibility(self._h, _vp(a), _vp(b), n, FLAG_BRUTE_FORCE if brute_force else 0, _vp(vis)))
+        return vis
+
+
+def untile(d_gathered_ptr: int, d_image_ptr: int, W: int, H: int, params: Params, stream: int = 0):
+    """[rank][local slot] packed framebuffers -> row-major W*H image (device pointers)."""
+    _check(load_library().hpt_untile(C.c_void_p(d_gathered_ptr), C.c_void_p(d_image_ptr), W, H, C.byref(params), C.c_void_p(stream)))
+
+
+def pt_render_wrapper(lights, spheres, triangles, camera, W, H, eye_depth, spp, seed=-1,
+                      scene_min=(0, 0, 0), scene_max=(0, 0, 0), light_depth=4, light_sample=8) -> np.ndarray:
+    """One-shot render with the reference's pt_render_wrapper argument list
+    (reference include/pt_cu.cuh:6-13)."""
+    lib = load_library()
+    lights = np.ascontiguousarray(lights, LIGHT)
+    spheres = np.ascontiguousarray(spheres, SPHERE)
+    triangles = np.ascontiguousarray(triangles, TRIANGLE)
+    cam = np.ascontiguousarray(camera, CAMERA).reshape(1)
+    img = np.empty((H, W, 3), np.float32)
+    mn = (C.c_float * 3)(*scene_min)
+    mx = (C.c_float * 3)(*scene_max)
+    _check(lib.hpt_pt_render_wrapper(_vp(lights), len(lights), _vp(spheres), len(spheres), _vp(triangles), len(triangles),
+                                     mn, mx, _vp(cam), _vp(img), W, H, light_depth, light_sample, eye_depth, spp,
+                                     C.c_int64(seed)))
+    return img

@@ -1,0 +1,417 @@
+// C ABI of libhpt.so (include/hpt.h): scene upload, the wavefront render loop, tiling and
+// the one-shot pt_render_wrapper equivalent.  Compiled with hipcc (host code only here).
+//
+// Render loop per pass (S samples of every local pixel in flight):
+//   generate -> repeat { extend, shade, connect } until the queue drains -> resolve
+// Queue counters live in device memory, one slot per iteration, so the host issues the first
+// eye_depth iterations without ever reading the device back; only scenes whose paths are still
+// alive after that (chains of free delta bounces, reference src/pt_cu.cu:228) cost one
+// counter read-back per extra iteration.
+#include "../../include/hpt.h"
+#include "hpt_scene.h"
+#include "pt_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+using namespace hpt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg){ g_err = msg; return code; }
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) \
+    return fail(HPT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while(0)
+
+template <typename T>
+hipError_t upload(const std::vector<T> &v, T **dptr){
+    *dptr = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **) dptr, bytes);
+    if(e != hipSuccess) return e;
+    if(!v.empty()) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+struct TimedLaunch { hipEvent_t a, b; int cls; };
+
+} // namespace
+
+struct hpt_scene {
+    SceneDev sd{};
+    BvhNode *d_nodes = nullptr; DevTriangle *d_tris = nullptr; DevRound *d_rounds = nullptr;
+    DevMaterial *d_mats = nullptr; DevLight *d_lights = nullptr;
+    int device = 0;
+
+    // workspace, grown on demand
+    size_t cap_paths = 0, cap_local = 0;
+    PathBuf pb{}; ShadowBuf sb{};
+    uint32_t *queue[2] = { nullptr, nullptr };
+    uint32_t *counters = nullptr; int n_counters = 0;
+    float4 *accum = nullptr;
+    WorkCounters *d_wc = nullptr;
+    uint32_t *h_count = nullptr;          // pinned read-back word
+    float *d_local_own = nullptr; size_t cap_local_own = 0;
+    float *d_image_own = nullptr; size_t cap_image_own = 0;
+
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr; bool ev_valid = false;
+    std::vector<TimedLaunch> timed; std::vector<hipEvent_t> event_pool; size_t event_next = 0;
+    hpt_stats stats{};
+    bool stats_pending = false; int last_flags = 0;
+};
+
+namespace {
+
+void free_workspace(hpt_scene *s){
+    hipFree(s->pb.org_eta); hipFree(s->pb.dir_flags); hipFree(s->pb.thr); hipFree(s->pb.col);
+    hipFree(s->pb.rng); hipFree(s->pb.hit);
+    hipFree(s->sb.org_max); hipFree(s->sb.dir_path); hipFree(s->sb.contrib);
+    hipFree(s->queue[0]); hipFree(s->queue[1]);
+    s->pb = PathBuf{}; s->sb = ShadowBuf{}; s->queue[0] = s->queue[1] = nullptr; s->cap_paths = 0;
+}
+
+int ensure_workspace(hpt_scene *s, size_t paths, size_t n_local, int n_counters){
+    if(paths > s->cap_paths){
+        free_workspace(s);
+        HIP_TRY(hipMalloc((void **) &s->pb.org_eta, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->pb.dir_flags, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->pb.thr, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->pb.col, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->pb.rng, paths * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **) &s->pb.hit, paths * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **) &s->sb.org_max, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->sb.dir_path, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->sb.contrib, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->queue[0], paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &s->queue[1], paths * sizeof(uint32_t)));
+        s->cap_paths = paths;
+    }
+    if(n_local > s->cap_local){
+        hipFree(s->accum); s->accum = nullptr;
+        HIP_TRY(hipMalloc((void **) &s->accum, n_local * sizeof(float4)));
+        s->cap_local = n_local;
+    }
+    if(n_counters > s->n_counters){
+        hipFree(s->counters); s->counters = nullptr;
+        HIP_TRY(hipMalloc((void **) &s->counters, (size_t) n_counters * sizeof(uint32_t)));
+        s->n_counters = n_counters;
+    }
+    if(!s->d_wc) HIP_TRY(hipMalloc((void **) &s->d_wc, sizeof(WorkCounters)));
+    if(!s->h_count) HIP_TRY(hipHostMalloc((void **) &s->h_count, 64));
+    if(!s->ev_start){ HIP_TRY(hipEventCreate(&s->ev_start)); HIP_TRY(hipEventCreate(&s->ev_stop)); }
+    return HPT_OK;
+}
+
+int make_tiling(int W, int H, const hpt_params *p, Tiling &tl){
+    if(W <= 0 || H <= 0) return fail(HPT_ERR_INVALID, "image size must be positive");
+    int world = (p && p->world > 1) ? p->world : 1;
+    int rank = (p && p->world > 1) ? p->rank : 0;
+    int tile = (p && p->tile > 0) ? p->tile : 32;
+    if(tile % 8 != 0 || tile > 1024) return fail(HPT_ERR_INVALID, "tile must be a multiple of 8 (<= 1024)");
+    if(rank < 0 || rank >= world) return fail(HPT_ERR_INVALID, "rank outside [0, world)");
+    tl.W = W; tl.H = H; tl.tile = tile;
+    tl.tiles_x = (W + tile - 1) / tile; tl.tiles_y = (H + tile - 1) / tile;
+    tl.ntiles = tl.tiles_x * tl.tiles_y;
+    tl.rank = rank; tl.world = world;
+    long long per_rank = (tl.ntiles + world - 1) / world;
+    long long n_local = per_rank * tile * tile;
+    if(n_local > 0x7FFFFFFFll) return fail(HPT_ERR_INVALID, "local framebuffer too large");
+    tl.n_local = (int) n_local;
+    return HPT_OK;
+}
+
+hipEvent_t pool_event(hpt_scene *s){
+    if(s->event_next == s->event_pool.size()){
+        hipEvent_t e; hipEventCreate(&e); s->event_pool.push_back(e);
+    }
+    return s->event_pool[s->event_next++];
+}
+
+struct LaunchTimer {        // brackets one launch with events when TIME_KERNELS is set
+    hpt_scene *s; hipStream_t st; bool on; TimedLaunch tl;
+    LaunchTimer(hpt_scene *s_, hipStream_t st_, bool on_, int cls) : s(s_), st(st_), on(on_) {
+        if(on){ tl.a = pool_event(s); tl.b = pool_event(s); tl.cls = cls; hipEventRecord(tl.a, st); }
+    }
+    ~LaunchTimer(){ if(on){ hipEventRecord(tl.b, st); s->timed.push_back(tl); } }
+};
+
+// the wavefront render loop; everything is enqueued on `stream`
+int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, int spp,
+                 const hpt_params *params, float *d_local, hipStream_t stream){
+    if(!s) return fail(HPT_ERR_INVALID, "null scene");
+    if(!camera || !d_local) return fail(HPT_ERR_INVALID, "null camera or output");
+    if(spp <= 0 || eye_depth <= 0 || eye_depth > 255) return fail(HPT_ERR_INVALID, "spp must be > 0 and eye_depth in [1, 255]");
+    hpt_params P; memset(&P, 0, sizeof P);
+    if(params) P = *params;
+    if(P.max_delta <= 0) P.max_delta = 64;
+    if(P.max_delta > 250) P.max_delta = 250;
+    Tiling tl;
+    int rc = make_tiling(W, H, &P, tl);
+    if(rc) return rc;
+
+    // samples in flight per pass: fill about 4M path slots
+    int spass = P.samples_per_pass;
+    if(spass <= 0){
+        const long long target = 4ll << 20;
+        spass = (int) std::max<long long>(1, target / tl.n_local);
+    }
+    spass = std::min(spass, spp);
+    size_t paths = (size_t) tl.n_local * spass;
+    if(paths > 0x7FFFFFF0ull) return fail(HPT_ERR_INVALID, "too many path slots per pass");
+    int max_iters = eye_depth + P.max_delta + 1;
+    int n_counters = 2 * (max_iters + 2);
+    rc = ensure_workspace(s, paths, tl.n_local, n_counters);
+    if(rc) return rc;
+
+    const float *cf = (const float *) camera;       // CudaCamera: eye, U, V, W, UL, dx, dy (12 B each)
+    CameraDev cam;
+    memcpy(cam.eye, cf + 0, 12); memcpy(cam.UL, cf + 12, 12); memcpy(cam.dx, cf + 15, 12); memcpy(cam.dy, cf + 18, 12);
+
+    const int flags = P.flags;
+    const bool count = (flags & HPT_FLAG_COUNT_WORK) != 0;
+    const bool timek = (flags & HPT_FLAG_TIME_KERNELS) != 0;
+    const int kflags = (flags & HPT_FLAG_BRUTE_FORCE ? 1 : 0) | (count ? 2 : 0);
+    WorkCounters *wc = count ? s->d_wc : nullptr;
+    s->timed.clear(); s->event_next = 0;
+    s->last_flags = flags;
+    s->stats.ms_total = s->stats.ms_extend = s->stats.ms_shade = s->stats.ms_connect = s->stats.ms_other = 0.0;
+    s->stats.n_extend = s->stats.n_shade = s->stats.n_connect = s->stats.n_other = 0;
+
+    HIP_TRY(hipMemsetAsync(s->d_wc, 0, sizeof(WorkCounters), stream));
+    HIP_TRY(hipMemsetAsync(s->accum, 0, (size_t) tl.n_local * sizeof(float4), stream));
+    HIP_TRY(hipEventRecord(s->ev_start, stream));
+
+    for(int done = 0; done < spp; done += spass){
+        int sthis = std::min(spass, spp - done);
+        uint32_t slots = (uint32_t) tl.n_local * (uint32_t) sthis;
+        HIP_TRY(hipMemsetAsync(s->counters, 0, (size_t) n_counters * sizeof(uint32_t), stream));
+        uint32_t *qcnt = s->counters;                 // qcnt[i]: paths entering iteration i
+        uint32_t *scnt = s->counters + (max_iters + 2);   // scnt[i]: shadow rays of iteration i
+        { LaunchTimer t(s, stream, timek, 3);
+          launch_generate(stream, tl, cam, s->pb, s->queue[0], &qcnt[0], sthis,
+                          (uint32_t) (P.sample_offset + done), P.seed, wc); }
+        int cur = 0;
+        for(int it = 0; it < max_iters; ++it){
+            if(it >= eye_depth){
+                // only free delta bounces can keep a path alive this long: look before launching
+                HIP_TRY(hipMemcpyAsync(s->h_count, &qcnt[it], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if(*s->h_count == 0u) break;
+            }
+            { LaunchTimer t(s, stream, timek, 0);
+              launch_extend(stream, s->sd, s->pb, s->queue[cur], &qcnt[it], slots, kflags, wc); }
+            { LaunchTimer t(s, stream, timek, 1);
+              launch_shade(stream, s->sd, s->pb, s->queue[cur], &qcnt[it], slots, s->queue[cur ^ 1], &qcnt[it + 1],
+                           s->sb, &scnt[it], eye_depth, P.max_delta, wc); }
+            { LaunchTimer t(s, stream, timek, 2);
+              launch_connect(stream, s->sd, s->pb, s->sb, &scnt[it], slots, kflags, wc); }
+            cur ^= 1;
+        }
+        { LaunchTimer t(s, stream, timek, 3);
+          launch_resolve(stream, tl, s->pb, s->accum, sthis); }
+    }
+    float divisor = (flags & HPT_FLAG_OUTPUT_SUM) ? 1.0f : (float) spp;
+    { LaunchTimer t(s, stream, timek, 3);
+      launch_finalize(stream, tl, s->accum, d_local, divisor); }
+    HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    HIP_TRY(hipGetLastError());
+    s->ev_valid = true;
+    s->stats_pending = true;
+    return HPT_OK;
+}
+
+int collect_stats(hpt_scene *s){
+    if(!s->stats_pending) return HPT_OK;
+    HIP_TRY(hipEventSynchronize(s->ev_stop));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
+    s->stats.ms_total = ms;
+    double sum[4] = { 0, 0, 0, 0 }; uint32_t cnt[4] = { 0, 0, 0, 0 };
+    for(const TimedLaunch &t : s->timed){
+        float e = 0.f;
+        if(hipEventElapsedTime(&e, t.a, t.b) == hipSuccess){ sum[t.cls] += e; cnt[t.cls]++; }
+    }
+    s->stats.ms_extend = sum[0]; s->stats.ms_shade = sum[1]; s->stats.ms_connect = sum[2]; s->stats.ms_other = sum[3];
+    s->stats.n_extend = cnt[0]; s->stats.n_shade = cnt[1]; s->stats.n_connect = cnt[2]; s->stats.n_other = cnt[3];
+    WorkCounters wc;
+    HIP_TRY(hipMemcpy(&wc, s->d_wc, sizeof wc, hipMemcpyDeviceToHost));
+    s->stats.samples = wc.samples; s->stats.closest_rays = wc.closest_rays; s->stats.shadow_rays = wc.shadow_rays;
+    s->stats.boxes_tested = wc.boxes; s->stats.tris_tested = wc.tris; s->stats.path_iters = wc.path_iters;
+    s->stats_pending = false;
+    return HPT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *hpt_last_error(void){ return g_err.c_str(); }
+
+int hpt_device_count(void){
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                     hpt_scene **out){
+    if(!out) return fail(HPT_ERR_INVALID, "null out_scene");
+    *out = nullptr;
+    HostScene hs;
+    const char *err = build_host_scene(lights, nl, spheres, ns, tris, nt, hs);
+    if(err && *err) return fail(HPT_ERR_INVALID, err);
+    hpt_scene *s = new hpt_scene();
+    auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipGetDevice(&s->device);
+    if(e == hipSuccess) e = upload(hs.nodes, &s->d_nodes);
+    if(e == hipSuccess) e = upload(hs.tris, &s->d_tris);
+    if(e == hipSuccess) e = upload(hs.rounds, &s->d_rounds);
+    if(e == hipSuccess) e = upload(hs.materials, &s->d_mats);
+    if(e == hipSuccess) e = upload(hs.lights, &s->d_lights);
+    if(e != hipSuccess){
+        std::string msg = std::string("scene upload: ") + hipGetErrorString(e);
+        hpt_scene_destroy(s);
+        return fail(HPT_ERR_DEVICE, msg);
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    s->sd.nodes = (const float4 *) s->d_nodes; s->sd.tris = (const float4 *) s->d_tris;
+    s->sd.rounds = s->d_rounds; s->sd.mats = s->d_mats; s->sd.lights = s->d_lights;
+    s->sd.num_rounds = ns + nl; s->sd.num_spheres = ns; s->sd.num_lights = nl; s->sd.num_tris = nt;
+    s->sd.num_mats = (int) hs.materials.size(); s->sd.pad = 0;
+    memset(&s->stats, 0, sizeof s->stats);
+    s->stats.bvh_nodes = (uint32_t) hs.nodes.size(); s->stats.bvh_depth = (uint32_t) hs.bvh_depth;
+    s->stats.n_tris = (uint32_t) nt; s->stats.n_materials = (uint32_t) hs.materials.size();
+    s->stats.ms_bvh_build = hs.ms_bvh_build;
+    s->stats.ms_upload = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    *out = s;
+    return HPT_OK;
+}
+
+void hpt_scene_destroy(hpt_scene *s){
+    if(!s) return;
+    free_workspace(s);
+    hipFree(s->accum); hipFree(s->counters); hipFree(s->d_wc);
+    if(s->h_count) hipHostFree(s->h_count);
+    hipFree(s->d_local_own); hipFree(s->d_image_own);
+    hipFree(s->d_nodes); hipFree(s->d_tris); hipFree(s->d_rounds); hipFree(s->d_mats); hipFree(s->d_lights);
+    if(s->ev_start) hipEventDestroy(s->ev_start);
+    if(s->ev_stop) hipEventDestroy(s->ev_stop);
+    for(hipEvent_t e : s->event_pool) hipEventDestroy(e);
+    delete s;
+}
+
+int64_t hpt_local_pixels(int W, int H, const hpt_params *params){
+    Tiling tl;
+    if(make_tiling(W, H, params, tl)) return -1;
+    return tl.n_local;
+}
+
+int hpt_render_pt_device(hpt_scene *scene, const void *camera, int W, int H, int eye_depth, int spp,
+                         const hpt_params *params, void *d_local, void *hip_stream){
+    return render_local(scene, camera, W, H, eye_depth, spp, params, (float *) d_local, (hipStream_t) hip_stream);
+}
+
+int hpt_untile(const void *d_gathered, void *d_image, int W, int H, const hpt_params *params, void *hip_stream){
+    Tiling tl;
+    int rc = make_tiling(W, H, params, tl);
+    if(rc) return rc;
+    if(!d_gathered || !d_image) return fail(HPT_ERR_INVALID, "null buffer");
+    launch_untile((hipStream_t) hip_stream, tl, (const float *) d_gathered, (float *) d_image);
+    HIP_TRY(hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_render_pt(hpt_scene *s, const void *camera, int W, int H, int eye_depth, int spp,
+                  const hpt_params *params, float *host_image){
+    if(!s) return fail(HPT_ERR_INVALID, "null scene");
+    if(!host_image) return fail(HPT_ERR_INVALID, "null image");
+    if(params && params->world > 1) return fail(HPT_ERR_INVALID, "hpt_render_pt renders the whole image: world must be 0 or 1");
+    Tiling tl;
+    int rc = make_tiling(W, H, params, tl);
+    if(rc) return rc;
+    size_t nloc = (size_t) tl.n_local * 3, nimg = (size_t) W * H * 3;
+    if(nloc > s->cap_local_own){
+        hipFree(s->d_local_own); s->d_local_own = nullptr; s->cap_local_own = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_local_own, nloc * sizeof(float)));
+        s->cap_local_own = nloc;
+    }
+    if(nimg > s->cap_image_own){
+        hipFree(s->d_image_own); s->d_image_own = nullptr; s->cap_image_own = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_image_own, nimg * sizeof(float)));
+        s->cap_image_own = nimg;
+    }
+    hipStream_t st = nullptr;
+    rc = render_local(s, camera, W, H, eye_depth, spp, params, s->d_local_own, st);
+    if(rc) return rc;
+    launch_untile(st, tl, s->d_local_own, s->d_image_own);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(host_image, s->d_image_own, nimg * sizeof(float), hipMemcpyDeviceToHost));
+    return HPT_OK;
+}
+
+int hpt_pt_render_wrapper(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                          const float scene_min[3], const float scene_max[3], const void *camera, float *host_image,
+                          int W, int H, int light_depth, int light_sample, int eye_depth, int spp, int64_t seed){
+    (void) scene_min; (void) scene_max; (void) light_depth; (void) light_sample;   // ignored by the reference too
+    hpt_scene *s = nullptr;
+    int rc = hpt_scene_create(lights, nl, spheres, ns, tris, nt, &s);
+    if(rc) return rc;
+    hpt_params p; memset(&p, 0, sizeof p);
+    p.seed = seed >= 0 ? (uint64_t) seed : (uint64_t) time(nullptr);      // reference: time(NULL), pt_cu.cu:282
+    rc = hpt_render_pt(s, camera, W, H, eye_depth, spp, &p, host_image);
+    std::string keep = g_err;
+    hpt_scene_destroy(s);
+    g_err = keep;
+    return rc;
+}
+
+int hpt_get_stats(const hpt_scene *scene, hpt_stats *out){
+    if(!scene || !out) return fail(HPT_ERR_INVALID, "null argument");
+    int rc = collect_stats(const_cast<hpt_scene *>(scene));
+    if(rc) return rc;
+    *out = scene->stats;
+    return HPT_OK;
+}
+
+int hpt_trace_closest(hpt_scene *s, const float *origins, const float *dirs, int n, int flags,
+                      float *t_out, int32_t *prim_out){
+    if(!s || !origins || !dirs || !t_out || !prim_out || n < 0) return fail(HPT_ERR_INVALID, "bad argument");
+    if(n == 0) return HPT_OK;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr; int32_t *d_p = nullptr;
+    size_t b3 = (size_t) n * 3 * sizeof(float);
+    HIP_TRY(hipMalloc((void **) &d_o, b3)); HIP_TRY(hipMalloc((void **) &d_d, b3));
+    HIP_TRY(hipMalloc((void **) &d_t, (size_t) n * 4)); HIP_TRY(hipMalloc((void **) &d_p, (size_t) n * 4));
+    HIP_TRY(hipMemcpy(d_o, origins, b3, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, dirs, b3, hipMemcpyHostToDevice));
+    launch_probe_closest(nullptr, s->sd, d_o, d_d, n, (flags & HPT_FLAG_BRUTE_FORCE) ? 1 : 0, d_t, d_p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(t_out, d_t, (size_t) n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(prim_out, d_p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_p);
+    return HPT_OK;
+}
+
+int hpt_trace_visibility(hpt_scene *s, const float *p1, const float *p2, int n, int flags, int32_t *vis_out){
+    if(!s || !p1 || !p2 || !vis_out || n < 0) return fail(HPT_ERR_INVALID, "bad argument");
+    if(n == 0) return HPT_OK;
+    float *d_a = nullptr, *d_b = nullptr; int32_t *d_v = nullptr;
+    size_t b3 = (size_t) n * 3 * sizeof(float);
+    HIP_TRY(hipMalloc((void **) &d_a, b3)); HIP_TRY(hipMalloc((void **) &d_b, b3));
+    HIP_TRY(hipMalloc((void **) &d_v, (size_t) n * 4));
+    HIP_TRY(hipMemcpy(d_a, p1, b3, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b, p2, b3, hipMemcpyHostToDevice));
+    launch_probe_visibility(nullptr, s->sd, d_a, d_b, n, (flags & HPT_FLAG_BRUTE_FORCE) ? 1 : 0, d_v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(vis_out, d_v, (size_t) n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_a); hipFree(d_b); hipFree(d_v);
+    return HPT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,78 @@
+// Device-side scene layout of the path-tracing hot path, shared by the host flattening /
+// BVH code (scene_build.cpp) and the HIP kernels (pt_kernels.hip).  Plain structs only.
+//
+// Everything is 16-byte records so one lane fetches a record with dwordx4 loads:
+//   BVH node      64 B  both children's boxes + child codes (one fetch tests two boxes)
+//   triangle      48 B  v0 | e1 = v1-v0 | e2 = v2-v0, in BVH leaf order
+//   round prim    32 B  spheres followed by light balls (the reference's scan order)
+//   material      32 B  de-duplicated CudaMaterial records
+//   light         80 B  CudaLight with the per-light invariants hoisted
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace hpt {
+
+constexpr uint32_t kLeafFlag = 0x80000000u;   // child code: leaf | first_tri << 3 | (count - 1)
+constexpr uint32_t kEmptyChild = 0xFFFFFFFFu; // child code of an absent child (box is inverted)
+constexpr int kMaxLeafTris = 4;
+constexpr int kMaxBvhDepth = 30;              // traversal stack holds kStackDepth entries
+constexpr int kStackDepth = 32;
+
+struct Float4 { float x, y, z, w; };
+
+struct BvhNode {           // 64 B
+    float lmin[3]; uint32_t left;
+    float lmax[3]; uint32_t right;
+    float rmin[3]; uint32_t pad0;
+    float rmax[3]; uint32_t pad1;
+};
+
+struct DevTriangle {       // 48 B
+    float v0[3]; uint32_t ordinal;   // reference scan ordinal (num_spheres + num_lights + input index)
+    float e1[3]; uint32_t material;  // index into the material table
+    float e2[3]; uint32_t flags;     // bit 0: opaque to shadow rays (mtl.eta <= 0)
+};
+
+struct DevRound {          // 32 B: sphere or light ball
+    float c[3]; float r;
+    uint32_t material;     // spheres: material index; light balls: light index
+    uint32_t flags;        // bit 0: opaque to shadow rays; bit 1: is a light ball
+    uint32_t pad[2];
+};
+
+struct DevMaterial {       // 32 B
+    float base[3]; float roughness;
+    float metallic; float eta; uint32_t type; uint32_t pad;
+};
+
+struct DevLight {          // 80 B
+    float pos[3]; float r;
+    float main_dir[3]; float cos_cutoff;     // normalize(dir); cosf(cutoff) from the host libm
+    float neg_dir[3]; float cutoff;          // normalize(dir * -1) for parallel lights
+    float illum[3]; float area;              // 4 * pi * r * r
+    uint32_t is_parallel; float cone_ratio;  // (1 - cos_cutoff) / 2
+    uint32_t pad[2];
+};
+
+static_assert(sizeof(BvhNode) == 64 && sizeof(DevTriangle) == 48 && sizeof(DevRound) == 32, "layout");
+static_assert(sizeof(DevMaterial) == 32 && sizeof(DevLight) == 80, "layout");
+
+// Host-side flattened scene, ready to upload.
+struct HostScene {
+    std::vector<BvhNode> nodes;        // nodes[0] is the root (always an inner node)
+    std::vector<DevTriangle> tris;     // leaf order
+    std::vector<DevRound> rounds;      // spheres, then light balls
+    std::vector<DevMaterial> materials;
+    std::vector<DevLight> lights;
+    int num_spheres = 0, num_lights = 0, num_tris = 0;
+    int bvh_depth = 0;
+    double ms_bvh_build = 0.0;
+};
+
+// Flattens reference records (layouts in include/hpt.h) and builds the BVH.
+// Returns an empty string on success, an error message otherwise.
+const char *build_host_scene(const void *lights, int nl, const void *spheres, int ns,
+                             const void *tris, int nt, HostScene &out);
+
+} // namespace hpt

@@ -1,0 +1,73 @@
+// Launch interface between the C ABI (hpt_api.cpp) and the HIP kernels (pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "hpt_scene.h"
+
+namespace hpt {
+
+struct SceneDev {
+    const float4 *nodes;        // BvhNode as 4 x float4
+    const float4 *tris;         // DevTriangle as 3 x float4, leaf order
+    const DevRound *rounds;     // spheres then light balls
+    const DevMaterial *mats;
+    const DevLight *lights;
+    int num_rounds, num_spheres, num_lights, num_tris, num_mats, pad;
+};
+
+// Path state, structure of arrays indexed by path slot (one slot per (pixel, sample) in flight).
+struct PathBuf {
+    float4 *org_eta;     // ray origin xyz | current medium eta
+    float4 *dir_flags;   // ray direction xyz | bit 0 last_is_delta, bits 8-15 depth, bits 16-23 delta count
+    float4 *thr;         // throughput xyz | unused
+    float4 *col;         // radiance accumulated by this sample xyz | unused
+    uint2 *rng;          // PCG32 state
+    uint2 *hit;          // extend result: as_uint(t) | primitive code
+};
+
+// Shadow-ray queue, structure of arrays indexed by queue position.
+struct ShadowBuf {
+    float4 *org_max;     // p1 xyz | max_d
+    float4 *dir_path;    // unit direction xyz | as_float(path slot)
+    float4 *contrib;     // clamped contribution if unoccluded xyz | unused
+};
+
+// Image tiling shared by ray generation, resolve and untile (see DESIGN.md "Tiling").
+struct Tiling {
+    int W, H, tile, tiles_x, tiles_y, ntiles, rank, world;
+    int n_local;         // packed local framebuffer slots = ceil(ntiles / world) * tile * tile
+};
+
+struct CameraDev { float eye[3], UL[3], dx[3], dy[3]; };
+
+struct WorkCounters {    // device counters, COUNT_WORK only
+    unsigned long long boxes, tris, closest_rays, shadow_rays, path_iters, samples;
+};
+
+// primitive code in PathBuf::hit.y
+constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
+constexpr uint32_t kHitRoundFlag = 0x80000000u;   // | index into rounds; else triangle slot
+
+constexpr int kBlock = 256;
+
+void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb, uint32_t *queue,
+                     uint32_t *qcount, int samples_this_pass, uint32_t first_sample, uint64_t seed,
+                     WorkCounters *wc);
+void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
+                   uint32_t max_items, int flags, WorkCounters *wc);
+void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
+                  uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *scount,
+                  int max_depth, int max_delta, WorkCounters *wc);
+void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *scount,
+                    uint32_t max_items, int flags, WorkCounters *wc);
+void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass);
+void launch_finalize(hipStream_t s, const Tiling &tl, const float4 *accum, float *d_local, float scale);
+void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, float *d_image);
+
+// ray-level probes (tests)
+void launch_probe_closest(hipStream_t s, const SceneDev &sc, const float *org, const float *dir, int n, int flags,
+                          float *t_out, int32_t *prim_out);
+void launch_probe_visibility(hipStream_t s, const SceneDev &sc, const float *p1, const float *p2, int n, int flags,
+                             int32_t *vis_out);
+
+} // namespace hpt

@@ -1,0 +1,649 @@
+// HIP kernels of the unidirectional path-tracing hot path, written for gfx950 (MI355X):
+// a wavefront pipeline over queues of path slots
+//
+//   generate -> [ extend -> shade -> connect ]* -> resolve -> finalize
+//
+// generate  primary rays for (pixel, sample) slots                 (reference src/pt_cu.cu:36-46)
+// extend    closest hit per queued path: spheres + light balls by scan, triangles by BVH
+//           (what it must return: reference include/geometric.cuh:327-388)
+// shade     light-hit emission, next-event estimation set-up, BSDF sampling, throughput
+//           update; survivors are compacted into the next queue with a wave64 ballot +
+//           mbcnt prefix and one atomic per wave          (reference src/pt_cu.cu:54-241)
+// connect   any-hit shadow rays; unoccluded contributions are added to the sample's radiance
+//           (reference include/geometric.cuh:293-325, src/pt_cu.cu:136-146,174-196)
+// resolve   per pixel, adds this pass's samples in sample order (src/pt_cu.cu:243-245)
+// finalize  mean over samples into the packed local framebuffer      (src/pt_cu.cu:248)
+//
+// One lane owns one path for the whole launch, every (pixel, sample) owns one slot for the
+// whole pass, and sums run in a fixed order, so results do not depend on scheduling, queue
+// order, pass size or the number of devices.  Built with -ffp-contract=off (pt_device_math.h).
+#include "pt_kernels.h"
+#include "pt_device_math.h"
+
+namespace hpt {
+
+namespace {
+
+HPT_DEV uint32_t f2u(float f){ return __float_as_uint(f); }
+HPT_DEV float u2f(uint32_t u){ return __uint_as_float(u); }
+HPT_DEV f3 xyz(float4 v){ return mk3(v.x, v.y, v.z); }
+
+// ---- wave64 queue push: ballot, mbcnt prefix, one atomic per wave ------------------------
+HPT_DEV uint32_t wave_push(bool want, uint32_t *counter){
+    unsigned long long mask = __ballot(want);
+    if(mask == 0ull) return 0u;
+    uint32_t lo = (uint32_t) mask, hi = (uint32_t) (mask >> 32);
+    uint32_t prefix = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    uint32_t total = (uint32_t) __popcll(mask);
+    uint32_t base = 0u;
+    int leader = __ffsll((long long) mask) - 1;
+    if((int) (threadIdx.x & 63u) == leader) base = atomicAdd(counter, total);
+    base = (uint32_t) __shfl((int) base, leader, 64);
+    return base + prefix;
+}
+
+// ---- tiling -----------------------------------------------------------------------------
+// local slot p -> global pixel; false when the slot lies outside the image
+HPT_DEV bool tile_to_pixel(const Tiling &tl, uint32_t p, int &x, int &y){
+    uint32_t ts2 = (uint32_t) (tl.tile * tl.tile);
+    uint32_t lt = p / ts2, q = p % ts2;
+    uint32_t gt = lt * (uint32_t) tl.world + (uint32_t) tl.rank;
+    if(gt >= (uint32_t) tl.ntiles) return false;
+    uint32_t tx = gt % (uint32_t) tl.tiles_x, ty = gt / (uint32_t) tl.tiles_x;
+    uint32_t sub = q >> 6, l = q & 63u;
+    uint32_t spr = (uint32_t) tl.tile >> 3;
+    uint32_t bx = sub % spr, by = sub / spr;
+    x = (int) (tx * (uint32_t) tl.tile + bx * 8u + (l & 7u));
+    y = (int) (ty * (uint32_t) tl.tile + by * 8u + (l >> 3));
+    return x < tl.W && y < tl.H;
+}
+
+// ---- traversal --------------------------------------------------------------------------
+struct Tally { uint32_t boxes, tris; };
+
+// Walks the triangle BVH.  ANY: returns true at the first opaque blocker in (1e-3, tmax).
+// Closest: refines (best_t, best_slot, best_ord); exact ties go to the lower scan ordinal,
+// which is what the reference's in-order scan with a strict '<' keeps.
+template <bool ANY, bool COUNT>
+HPT_DEV bool walk_bvh(const SceneDev &sc, f3 ro, f3 rd, float tmax, uint32_t *stk,
+                      float &best_t, uint32_t &best_slot, uint32_t &best_ord, Tally &tally){
+    float dx = fabsf(rd.x) > 1e-20f ? rd.x : copysignf(1e-20f, rd.x);
+    float dy = fabsf(rd.y) > 1e-20f ? rd.y : copysignf(1e-20f, rd.y);
+    float dz = fabsf(rd.z) > 1e-20f ? rd.z : copysignf(1e-20f, rd.z);
+    float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    float ox = ro.x * ix, oy = ro.y * iy, oz = ro.z * iz;
+    float limit = ANY ? tmax : best_t;
+    uint32_t cur = 0u;
+    int sp = 0;
+    for(;;){
+        bool descend = false;
+        if(!(cur & kLeafFlag)){
+            const float4 *n = sc.nodes + (size_t) cur * 4;
+            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if(COUNT) tally.boxes += 2;
+            float a0 = fmaf(n0.x, ix, -ox), a1 = fmaf(n1.x, ix, -ox);
+            float b0 = fmaf(n0.y, iy, -oy), b1 = fmaf(n1.y, iy, -oy);
+            float c0 = fmaf(n0.z, iz, -oz), c1 = fmaf(n1.z, iz, -oz);
+            float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+            float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
+            a0 = fmaf(n2.x, ix, -ox); a1 = fmaf(n3.x, ix, -ox);
+            b0 = fmaf(n2.y, iy, -oy); b1 = fmaf(n3.y, iy, -oy);
+            c0 = fmaf(n2.z, iz, -oz); c1 = fmaf(n3.z, iz, -oz);
+            float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+            float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
+            uint32_t lc = f2u(n0.w), rc = f2u(n1.w);
+            bool hl = (ln <= lf * 1.000002f) && (lc != kEmptyChild);
+            bool hr = (rn <= rf * 1.000002f) && (rc != kEmptyChild);
+            if(hl && hr){
+                bool left_first = ln <= rn;
+                stk[sp * kBlock] = left_first ? rc : lc;
+                ++sp;
+                cur = left_first ? lc : rc;
+                descend = true;
+            } else if(hl){ cur = lc; descend = true; }
+            else if(hr){ cur = rc; descend = true; }
+        } else {
+            uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
+            uint32_t cnt = (cur & 7u) + 1u;
+            for(uint32_t k = 0; k < cnt; ++k){
+                const float4 *tp = sc.tris + (size_t) (first + k) * 3;
+                float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                if(COUNT) tally.tris += 1;
+                float t;
+                if(hit_triangle(ro, rd, xyz(t0), xyz(t1), xyz(t2), ANY ? tmax : 1e20f, t)){
+                    if(ANY){
+                        if(t > 1e-3f && (f2u(t2.w) & 1u)) return true;
+                    } else {
+                        uint32_t ord = f2u(t0.w);
+                        if(t < best_t || (t == best_t && ord < best_ord)){
+                            best_t = t; best_slot = first + k; best_ord = ord; limit = t;
+                        }
+                    }
+                }
+            }
+        }
+        if(!descend){
+            if(sp == 0) break;
+            --sp;
+            cur = stk[sp * kBlock];
+        }
+    }
+    return false;
+}
+
+// Reference-order scan over every triangle (tests: BVH == scan).
+template <bool ANY, bool COUNT>
+HPT_DEV bool scan_tris(const SceneDev &sc, f3 ro, f3 rd, float tmax,
+                       float &best_t, uint32_t &best_slot, uint32_t &best_ord, Tally &tally){
+    for(int s = 0; s < sc.num_tris; ++s){
+        const float4 *tp = sc.tris + (size_t) s * 3;
+        float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+        if(COUNT) tally.tris += 1;
+        float t;
+        if(hit_triangle(ro, rd, xyz(t0), xyz(t1), xyz(t2), ANY ? tmax : 1e20f, t)){
+            if(ANY){
+                if(t > 1e-3f && (f2u(t2.w) & 1u)) return true;
+            } else {
+                uint32_t ord = f2u(t0.w);
+                if(t < best_t || (t == best_t && ord < best_ord)){ best_t = t; best_slot = (uint32_t) s; best_ord = ord; }
+            }
+        }
+    }
+    return false;
+}
+
+// closest hit over spheres, light balls (scan order) and triangles; returns t and primitive code
+template <bool BRUTE, bool COUNT>
+HPT_DEV void closest_hit(const SceneDev &sc, f3 ro, f3 rd, uint32_t *stk, float &t_out, uint32_t &prim_out, Tally &tally){
+    float best_t = 1e20f;
+    uint32_t best_prim = kHitMiss, best_ord = 0xFFFFFFFFu;
+    for(int i = 0; i < sc.num_rounds; ++i){
+        DevRound r = sc.rounds[i];
+        float t;
+        if(hit_sphere(ro, rd, mk3(r.c[0], r.c[1], r.c[2]), r.r, 1e20f, t) && t < best_t){
+            best_t = t; best_prim = kHitRoundFlag | (uint32_t) i; best_ord = (uint32_t) i;
+        }
+    }
+    uint32_t slot = 0xFFFFFFFFu;
+    float bt = best_t;
+    if(BRUTE) scan_tris<false, COUNT>(sc, ro, rd, 1e20f, bt, slot, best_ord, tally);
+    else walk_bvh<false, COUNT>(sc, ro, rd, 1e20f, stk, bt, slot, best_ord, tally);
+    if(slot != 0xFFFFFFFFu){ best_t = bt; best_prim = slot; }
+    t_out = best_t; prim_out = best_prim;
+}
+
+// shadow segment origin p1, unit direction, range (1e-3, max_d): true when unoccluded
+template <bool BRUTE, bool COUNT>
+HPT_DEV bool segment_visible(const SceneDev &sc, f3 p1, f3 dir, float max_d, uint32_t *stk, Tally &tally){
+    for(int i = 0; i < sc.num_spheres; ++i){
+        DevRound r = sc.rounds[i];
+        float t;
+        if(hit_sphere(p1, dir, mk3(r.c[0], r.c[1], r.c[2]), r.r, max_d, t) && t > 1e-3f && (r.flags & 1u)) return false;
+    }
+    float bt = max_d; uint32_t slot = 0, ord = 0;
+    bool blocked = BRUTE ? scan_tris<true, COUNT>(sc, p1, dir, max_d, bt, slot, ord, tally)
+                         : walk_bvh<true, COUNT>(sc, p1, dir, max_d, stk, bt, slot, ord, tally);
+    return !blocked;
+}
+
+HPT_DEV void flush_tally(const Tally &tally, uint32_t rays, WorkCounters *wc, bool shadow){
+    // wave reduction, then one atomic per wave and counter
+    unsigned long long b = tally.boxes, t = tally.tris, r = rays;
+    for(int off = 32; off > 0; off >>= 1){
+        b += __shfl_down(b, off, 64); t += __shfl_down(t, off, 64); r += __shfl_down(r, off, 64);
+    }
+    if((threadIdx.x & 63u) == 0u){
+        if(b) atomicAdd(&wc->boxes, b);
+        if(t) atomicAdd(&wc->tris, t);
+        if(r) atomicAdd(shadow ? &wc->shadow_rays : &wc->closest_rays, r);
+    }
+}
+
+// ---- kernels ----------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock)
+void k_generate(Tiling tl, CameraDev cam, PathBuf pb, uint32_t *queue, uint32_t *qcount,
+                uint32_t total, uint32_t first_sample, uint64_t seed, WorkCounters *wc){
+    uint32_t stride = gridDim.x * kBlock;
+    uint32_t rounds = (total + stride - 1) / stride;
+    for(uint32_t it = 0; it < rounds; ++it){
+        uint32_t i = it * stride + blockIdx.x * kBlock + threadIdx.x;
+        bool active = false;
+        if(i < total){
+            uint32_t p = i % (uint32_t) tl.n_local, j = i / (uint32_t) tl.n_local;
+            int px, py;
+            active = tile_to_pixel(tl, p, px, py);
+            if(active){
+                uint64_t rs = rng_seed(seed, (uint32_t) (py * tl.W + px), first_sample + j);
+                float pixel_x = (float) px + rng_next(rs);
+                float pixel_y = (float) py + rng_next(rs);
+                f3 eye = mk3(cam.eye[0], cam.eye[1], cam.eye[2]);
+                f3 pixel_pos = mk3(cam.UL[0], cam.UL[1], cam.UL[2]) + mk3(cam.dx[0], cam.dx[1], cam.dx[2]) * pixel_x
+                               + mk3(cam.dy[0], cam.dy[1], cam.dy[2]) * pixel_y;
+                f3 dir = normalize3(pixel_pos - eye);
+                pb.org_eta[i] = make_float4(eye.x, eye.y, eye.z, 1.0f);
+                pb.dir_flags[i] = make_float4(dir.x, dir.y, dir.z, u2f(1u));      // last_is_delta = true, depth 0
+                pb.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                pb.rng[i] = make_uint2((uint32_t) rs, (uint32_t) (rs >> 32));
+            }
+            pb.col[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        uint32_t pos = wave_push(active, qcount);
+        if(active) queue[pos] = i;
+        if(wc){
+            unsigned long long m = __ballot(active);
+            if((threadIdx.x & 63u) == 0u && m) atomicAdd(&wc->samples, (unsigned long long) __popcll(m));
+        }
+    }
+}
+
+template <bool BRUTE, bool COUNT>
+__global__ __launch_bounds__(kBlock)
+void k_extend(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount, WorkCounters *wc){
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    uint32_t count = *qcount;
+    uint32_t *stk = s_stack + threadIdx.x;
+    Tally tally; tally.boxes = 0; tally.tris = 0;
+    uint32_t rays = 0;
+    for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock){
+        uint32_t path = queue[i];
+        float4 o = pb.org_eta[path], d = pb.dir_flags[path];
+        float t; uint32_t prim;
+        closest_hit<BRUTE, COUNT>(sc, xyz(o), xyz(d), stk, t, prim, tally);
+        pb.hit[path] = make_uint2(f2u(t), prim);
+        ++rays;
+    }
+    if(COUNT) flush_tally(tally, rays, wc, false);
+}
+
+template <bool BRUTE, bool COUNT>
+__global__ __launch_bounds__(kBlock)
+void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *scount, WorkCounters *wc){
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    uint32_t count = *scount;
+    uint32_t *stk = s_stack + threadIdx.x;
+    Tally tally; tally.boxes = 0; tally.tris = 0;
+    uint32_t rays = 0;
+    for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock){
+        float4 a = sb.org_max[i], b = sb.dir_path[i];
+        bool vis = segment_visible<BRUTE, COUNT>(sc, xyz(a), xyz(b), a.w, stk, tally);
+        ++rays;
+        if(vis){
+            uint32_t path = f2u(b.w);
+            float4 c = sb.contrib[i];
+            float4 col = pb.col[path];
+            col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
+            pb.col[path] = col;
+        }
+    }
+    if(COUNT) flush_tally(tally, rays, wc, true);
+}
+
+constexpr int kLdsMats = 256;    // material records staged in LDS (8 KiB)
+constexpr int kLdsLights = 64;   // light records staged in LDS (5 KiB)
+
+__global__ __launch_bounds__(kBlock)
+void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
+             uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *scount,
+             int max_depth, int max_delta, WorkCounters *wc){
+    __shared__ DevMaterial s_mats[kLdsMats];
+    __shared__ DevLight s_lights[kLdsLights];
+    const bool mats_in_lds = sc.num_mats <= kLdsMats;
+    const bool lights_in_lds = sc.num_lights <= kLdsLights;
+    if(mats_in_lds){
+        const uint32_t *src = (const uint32_t *) sc.mats; uint32_t *dst = (uint32_t *) s_mats;
+        for(int w = threadIdx.x; w < sc.num_mats * 8; w += kBlock) dst[w] = src[w];
+    }
+    if(lights_in_lds){
+        const uint32_t *src = (const uint32_t *) sc.lights; uint32_t *dst = (uint32_t *) s_lights;
+        for(int w = threadIdx.x; w < sc.num_lights * 20; w += kBlock) dst[w] = src[w];
+    }
+    __syncthreads();
+    const DevMaterial *mats = mats_in_lds ? s_mats : sc.mats;
+    const DevLight *lights = lights_in_lds ? s_lights : sc.lights;
+
+    uint32_t count = *qcount;
+    uint32_t stride = gridDim.x * kBlock;
+    uint32_t rounds = (count + stride - 1) / stride;
+    uint32_t iters = 0;
+    for(uint32_t it = 0; it < rounds; ++it){
+        uint32_t i = it * stride + blockIdx.x * kBlock + threadIdx.x;
+        bool alive = false, want_shadow = false;
+        uint32_t path = 0;
+        f3 s_p1 = mk3(0, 0, 0), s_p2 = mk3(0, 0, 0), s_contrib = mk3(0, 0, 0);
+        if(i < count){
+            path = queue[i];
+            ++iters;
+            uint2 h = pb.hit[path];
+            uint32_t prim = h.y;
+            if(prim != kHitMiss){                                     // miss ends the path (pt_cu.cu:54)
+                float t = u2f(h.x);
+                float4 o4 = pb.org_eta[path], d4 = pb.dir_flags[path], th4 = pb.thr[path];
+                f3 ro = xyz(o4), rd = xyz(d4), throughput = xyz(th4);
+                float ray_eta = o4.w;
+                uint32_t flags = f2u(d4.w);
+                bool last_is_delta = (flags & 1u) != 0u;
+                int depth = (int) ((flags >> 8) & 0xFFu);
+                int delta_count = (int) ((flags >> 16) & 0xFFu);
+                f3 pos = ro + rd * t;
+                f3 wo = rd * -1.0f;
+                f3 normal; uint32_t mat_idx = 0; bool is_light = false; uint32_t light_idx = 0;
+                if(prim & kHitRoundFlag){
+                    DevRound r = sc.rounds[prim & 0x7FFFFFFFu];
+                    normal = normalize3(pos - mk3(r.c[0], r.c[1], r.c[2]));
+                    is_light = (r.flags & 2u) != 0u;
+                    mat_idx = r.material; light_idx = r.material;
+                } else {
+                    const float4 *tp = sc.tris + (size_t) prim * 3;
+                    float4 t1 = tp[1], t2 = tp[2];
+                    normal = normalize3(cross3(xyz(t1), xyz(t2)));
+                    mat_idx = f2u(t1.w);
+                }
+                if(dot3(normal, rd) > 0.0f) normal = normal * -1.0f;
+
+                if(is_light){                                          // pt_cu.cu:59-122
+                    const DevLight &hl = lights[light_idx];
+                    f3 emission = mk3(hl.illum[0], hl.illum[1], hl.illum[2]);
+                    float area = 1.0f, cone_ratio = 1.0f;
+                    bool valid_light = false;
+                    for(int li = 0; li < sc.num_lights; ++li){
+                        const DevLight &L = lights[li];
+                        f3 c2h = pos - mk3(L.pos[0], L.pos[1], L.pos[2]);
+                        if(fabsf(length3(c2h) - L.r) < 1e-2f){
+                            valid_light = true;
+                            area = L.area;
+                            if(L.cutoff > 0.0f && !L.is_parallel){
+                                cone_ratio = L.cone_ratio;
+                                if(depth == 0) cone_ratio = 1.f;
+                                else if(dot3(mk3(L.main_dir[0], L.main_dir[1], L.main_dir[2]), normalize3(c2h)) < L.cos_cutoff) cone_ratio = 0.0f;
+                            }
+                            break;
+                        }
+                    }
+                    if(valid_light && cone_ratio > 0.0f) emission = emission / (area * cone_ratio);
+                    else emission = mk3(0, 0, 0);
+                    if((emission.x > 0.0f || emission.y > 0.0f || emission.z > 0.0f) && last_is_delta){
+                        f3 contrib = throughput * emission;
+                        if(is_valid_color(contrib)){
+                            f3 c = clamp_radiance(contrib, 15.0f);
+                            float4 col = pb.col[path];
+                            col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
+                            pb.col[path] = col;
+                        }
+                    }
+                    // BSDF-sampled light hits after a non-delta bounce add nothing (the reference's
+                    // MIS branch is a stub with pdf_light_dir = 0, pt_cu.cu:103-118); path ends here.
+                } else {
+                    DevMaterial dm = mats[mat_idx];
+                    Mat m; m.base = mk3(dm.base[0], dm.base[1], dm.base[2]);
+                    m.roughness = dm.roughness; m.metallic = dm.metallic; m.eta = dm.eta;
+                    uint2 r2 = pb.rng[path];
+                    uint64_t rs = ((uint64_t) r2.y << 32) | (uint64_t) r2.x;
+
+                    // next-event estimation, pt_cu.cu:125-202
+                    if(m.eta <= 0.0f && (m.metallic < 0.99f || m.roughness > 0.01f) && sc.num_lights > 0){
+                        int l_idx = min((int) (rng_next(rs) * sc.num_lights), sc.num_lights - 1);
+                        const DevLight &L = lights[l_idx];
+                        f3 illum = mk3(L.illum[0], L.illum[1], L.illum[2]);
+                        if(L.is_parallel){
+                            f3 light_dir = mk3(L.neg_dir[0], L.neg_dir[1], L.neg_dir[2]);
+                            float cos_surface = fmaxf(0.0f, dot3(normal, light_dir));
+                            if(cos_surface > 0.0f){
+                                f3 brdf; float pdf_unused;
+                                bsdf_eval_pdf(m, wo, light_dir, normal, brdf, pdf_unused);
+                                f3 contrib = throughput * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface * (float) sc.num_lights;
+                                if(is_valid_color(contrib)){
+                                    want_shadow = true;
+                                    s_p1 = pos + normal * kEps;
+                                    s_p2 = pos + light_dir * 1e4f;
+                                    s_contrib = clamp_radiance(contrib, 15.0f);
+                                }
+                            }
+                        } else {
+                            f3 d_local;
+                            do {
+                                float a = rng_next(rs), b = rng_next(rs), c = rng_next(rs);
+                                d_local = mk3(a, b, c) * 2.0f - mk3(1.0f, 1.0f, 1.0f);
+                            } while(dot3(d_local, d_local) >= 1.0f);
+                            if(length3(d_local) > 0.001f) d_local = normalize3(d_local);
+                            else d_local = mk3(0, 1, 0);
+                            f3 light_pos = mk3(L.pos[0], L.pos[1], L.pos[2]) + d_local * L.r;
+                            f3 wi_light = light_pos - pos;
+                            float dist2 = dot3(wi_light, wi_light);
+                            float dist = sqrtf(dist2);
+                            wi_light = wi_light / dist;
+                            float cos_surface = fmaxf(0.0f, dot3(normal, wi_light));
+                            float cos_light = fmaxf(0.0f, dot3(d_local, wi_light * -1.0f));
+                            if(cos_surface > 0.0f && cos_light > 0.0f){
+                                bool inside_cone = true;
+                                if(L.cutoff > 0.0f){
+                                    if(dot3(mk3(L.main_dir[0], L.main_dir[1], L.main_dir[2]), wi_light * -1.0f) < L.cos_cutoff) inside_cone = false;
+                                }
+                                if(inside_cone){
+                                    float pdf_light_area = 1.0f / (sc.num_lights * L.area);
+                                    float pdf_light_dir = pdf_light_area * dist2 / fmaxf(cos_light, 1e-6f);
+                                    f3 brdf; float pdf_bsdf;
+                                    bsdf_eval_pdf(m, wo, wi_light, normal, brdf, pdf_bsdf);
+                                    float p_l = pdf_light_dir * pdf_light_dir;
+                                    float p_b = pdf_bsdf * pdf_bsdf;
+                                    float mis_w = p_l / fmaxf(p_l + p_b, 1e-8f);
+                                    f3 contrib = throughput * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface / pdf_light_dir * mis_w;
+                                    if(is_valid_color(contrib)){
+                                        want_shadow = true;
+                                        s_p1 = pos + normal * kEps;
+                                        s_p2 = light_pos + d_local * kEps;
+                                        s_contrib = clamp_radiance(contrib, 15.0f);
+                                    }
+                                }
+                            }
+                        }
+                    }
+
+                    // BSDF sampling and path continuation, pt_cu.cu:204-241
+                    float u_rr = rng_next(rs), u1 = rng_next(rs), u2 = rng_next(rs);
+                    f3 wi, bsdf_val; float pdf_omega, new_eta; bool is_delta;
+                    bsdf_sample(m, wo, normal, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
+                    if(!(pdf_omega <= 0.0f)){          // pt_cu.cu:214 (and the TIR return, defined: terminate)
+                        f3 new_o;
+                        if(is_delta){
+                            throughput = throughput * bsdf_val;
+                            ray_eta = new_eta;
+                            if(dot3(wi, normal) < 0.0f) new_o = pos - normal * kEps;
+                            else new_o = pos + normal * kEps;
+                            last_is_delta = true;
+                            ++delta_count;
+                            alive = is_valid_color(throughput) && delta_count <= max_delta;
+                        } else {
+                            float cos_wi = fabsf(dot3(normal, wi));
+                            throughput = throughput * bsdf_val * cos_wi / pdf_omega;
+                            new_o = pos + normal * kEps;
+                            last_is_delta = false;
+                            ++depth;
+                            alive = is_valid_color(throughput) && depth < max_depth;
+                        }
+                        if(alive){
+                            uint32_t nf = (last_is_delta ? 1u : 0u) | ((uint32_t) depth << 8) | ((uint32_t) delta_count << 16);
+                            pb.org_eta[path] = make_float4(new_o.x, new_o.y, new_o.z, ray_eta);
+                            pb.dir_flags[path] = make_float4(wi.x, wi.y, wi.z, u2f(nf));
+                            pb.thr[path] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+                            pb.rng[path] = make_uint2((uint32_t) rs, (uint32_t) (rs >> 32));
+                        }
+                    }
+                }
+            }
+        }
+        uint32_t spos = wave_push(want_shadow, scount);
+        if(want_shadow){
+            f3 diff = s_p2 - s_p1;                          // geometric.cuh:298-303
+            float dist = length3(diff);
+            f3 dir = diff / dist;
+            sb.org_max[spos] = make_float4(s_p1.x, s_p1.y, s_p1.z, dist - 1e-3f);
+            sb.dir_path[spos] = make_float4(dir.x, dir.y, dir.z, u2f(path));
+            sb.contrib[spos] = make_float4(s_contrib.x, s_contrib.y, s_contrib.z, 0.0f);
+        }
+        uint32_t qpos = wave_push(alive, next_count);
+        if(alive) next_queue[qpos] = path;
+    }
+    if(wc){
+        unsigned long long v = iters;
+        for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if((threadIdx.x & 63u) == 0u && v) atomicAdd(&wc->path_iters, v);
+    }
+}
+
+// accum[p] += sum over this pass's samples, in sample order, after the per-sample guard
+__global__ __launch_bounds__(kBlock)
+void k_resolve(Tiling tl, PathBuf pb, float4 *accum, int samples){
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if(p >= (uint32_t) tl.n_local) return;
+    float4 a = accum[p];
+    f3 sum = mk3(a.x, a.y, a.z);
+    for(int j = 0; j < samples; ++j){
+        float4 c4 = pb.col[(size_t) j * tl.n_local + p];
+        f3 c = xyz(c4);
+        if(!is_valid_color(c)) c = mk3(0, 0, 0);            // pt_cu.cu:243
+        sum = sum + c;                                      // pt_cu.cu:245
+    }
+    accum[p] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+}
+
+// d_local[p] = accum[p] / spp (scale_is_div) -- pt_cu.cu:248
+__global__ __launch_bounds__(kBlock)
+void k_finalize(Tiling tl, const float4 *accum, float *d_local, float divisor){
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if(p >= (uint32_t) tl.n_local) return;
+    float4 a = accum[p];
+    f3 v = mk3(a.x, a.y, a.z);
+    if(divisor != 1.0f) v = v / divisor;
+    d_local[(size_t) p * 3 + 0] = v.x;
+    d_local[(size_t) p * 3 + 1] = v.y;
+    d_local[(size_t) p * 3 + 2] = v.z;
+}
+
+// row-major image <- [rank][local slot] packed buffers
+__global__ __launch_bounds__(kBlock)
+void k_untile(Tiling tl, const float *gathered, float *image){
+    uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    if(idx >= (uint32_t) (tl.W * tl.H)) return;
+    uint32_t x = idx % (uint32_t) tl.W, y = idx / (uint32_t) tl.W;
+    uint32_t ts = (uint32_t) tl.tile;
+    uint32_t tx = x / ts, ty = y / ts;
+    uint32_t gt = ty * (uint32_t) tl.tiles_x + tx;
+    uint32_t r = gt % (uint32_t) tl.world, lt = gt / (uint32_t) tl.world;
+    uint32_t bx = (x % ts) >> 3, by = (y % ts) >> 3;
+    uint32_t l = ((y & 7u) << 3) | (x & 7u);
+    uint32_t q = (by * (ts >> 3) + bx) * 64u + l;
+    size_t src = ((size_t) r * tl.n_local + (size_t) lt * ts * ts + q) * 3;
+    size_t dst = (size_t) idx * 3;
+    image[dst + 0] = gathered[src + 0];
+    image[dst + 1] = gathered[src + 1];
+    image[dst + 2] = gathered[src + 2];
+}
+
+template <bool BRUTE>
+__global__ __launch_bounds__(kBlock)
+void k_probe_closest(SceneDev sc, const float *org, const float *dir, int n, float *t_out, int32_t *prim_out){
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if(i >= n) return;
+    Tally tally; tally.boxes = 0; tally.tris = 0;
+    float t; uint32_t prim;
+    closest_hit<BRUTE, false>(sc, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
+                              s_stack + threadIdx.x, t, prim, tally);
+    int32_t ord = -1;
+    if(prim != kHitMiss){
+        if(prim & kHitRoundFlag) ord = (int32_t) (prim & 0x7FFFFFFFu);
+        else ord = (int32_t) f2u(sc.tris[(size_t) prim * 3].w);
+    }
+    t_out[i] = t; prim_out[i] = ord;
+}
+
+template <bool BRUTE>
+__global__ __launch_bounds__(kBlock)
+void k_probe_visibility(SceneDev sc, const float *p1, const float *p2, int n, int32_t *vis_out){
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if(i >= n) return;
+    Tally tally; tally.boxes = 0; tally.tris = 0;
+    f3 a = mk3(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]), b = mk3(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]);
+    f3 diff = b - a;
+    float dist = length3(diff);
+    f3 d = diff / dist;
+    vis_out[i] = segment_visible<BRUTE, false>(sc, a, d, dist - 1e-3f, s_stack + threadIdx.x, tally) ? 1 : 0;
+}
+
+uint32_t grid_for(uint32_t items){
+    uint32_t g = (items + kBlock - 1) / kBlock;
+    if(g < 1u) g = 1u;
+    return g > 2048u ? 2048u : g;       // persistent grid-stride loops above 2048 workgroups
+}
+
+} // namespace
+
+// ---- launchers --------------------------------------------------------------------------
+
+void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb, uint32_t *queue,
+                     uint32_t *qcount, int samples_this_pass, uint32_t first_sample, uint64_t seed,
+                     WorkCounters *wc){
+    uint32_t total = (uint32_t) tl.n_local * (uint32_t) samples_this_pass;
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(total)), dim3(kBlock), 0, s, tl, cam, pb, queue, qcount, total,
+                       first_sample, seed, wc);
+}
+
+void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
+                   uint32_t max_items, int flags, WorkCounters *wc){
+    dim3 g(grid_for(max_items)), b(kBlock);
+    bool brute = flags & 1, count = flags & 2;
+    if(brute && count) hipLaunchKernelGGL((k_extend<true, true>), g, b, 0, s, sc, pb, queue, qcount, wc);
+    else if(brute) hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, s, sc, pb, queue, qcount, wc);
+    else if(count) hipLaunchKernelGGL((k_extend<false, true>), g, b, 0, s, sc, pb, queue, qcount, wc);
+    else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, s, sc, pb, queue, qcount, wc);
+}
+
+void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
+                  uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *scount,
+                  int max_depth, int max_delta, WorkCounters *wc){
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(max_items)), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
+                       next_count, sb, scount, max_depth, max_delta, wc);
+}
+
+void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *scount,
+                    uint32_t max_items, int flags, WorkCounters *wc){
+    dim3 g(grid_for(max_items)), b(kBlock);
+    bool brute = flags & 1, count = flags & 2;
+    if(brute && count) hipLaunchKernelGGL((k_connect<true, true>), g, b, 0, s, sc, pb, sb, scount, wc);
+    else if(brute) hipLaunchKernelGGL((k_connect<true, false>), g, b, 0, s, sc, pb, sb, scount, wc);
+    else if(count) hipLaunchKernelGGL((k_connect<false, true>), g, b, 0, s, sc, pb, sb, scount, wc);
+    else hipLaunchKernelGGL((k_connect<false, false>), g, b, 0, s, sc, pb, sb, scount, wc);
+}
+
+void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass){
+    uint32_t g = ((uint32_t) tl.n_local + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_resolve, dim3(g), dim3(kBlock), 0, s, tl, pb, accum, samples_this_pass);
+}
+
+void launch_finalize(hipStream_t s, const Tiling &tl, const float4 *accum, float *d_local, float divisor){
+    uint32_t g = ((uint32_t) tl.n_local + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_finalize, dim3(g), dim3(kBlock), 0, s, tl, accum, d_local, divisor);
+}
+
+void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, float *d_image){
+    uint32_t g = ((uint32_t) (tl.W * tl.H) + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_untile, dim3(g), dim3(kBlock), 0, s, tl, d_gathered, d_image);
+}
+
+void launch_probe_closest(hipStream_t s, const SceneDev &sc, const float *org, const float *dir, int n, int flags,
+                          float *t_out, int32_t *prim_out){
+    dim3 g((n + kBlock - 1) / kBlock), b(kBlock);
+    if(flags & 1) hipLaunchKernelGGL((k_probe_closest<true>), g, b, 0, s, sc, org, dir, n, t_out, prim_out);
+    else hipLaunchKernelGGL((k_probe_closest<false>), g, b, 0, s, sc, org, dir, n, t_out, prim_out);
+}
+
+void launch_probe_visibility(hipStream_t s, const SceneDev &sc, const float *p1, const float *p2, int n, int flags,
+                             int32_t *vis_out){
+    dim3 g((n + kBlock - 1) / kBlock), b(kBlock);
+    if(flags & 1) hipLaunchKernelGGL((k_probe_visibility<true>), g, b, 0, s, sc, p1, p2, n, vis_out);
+    else hipLaunchKernelGGL((k_probe_visibility<false>), g, b, 0, s, sc, p1, p2, n, vis_out);
+}
+
+} // namespace hpt
