@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X path-tracing hot path (BASELINE.json metric).
+
+One "step" = one full render of the workload: BASELINE.json configs[2] -- unidirectional PT
+with NEE, Cornell-style box + ~100k-triangle tessellated sphere behind a BVH, 1024 x 1024,
+256 spp, depth 4 -- with the scene and BVH already resident in HBM.  With N > 1 ranks (one
+process per GPU, launched by torch.distributed.run) the image's tiles are dealt round-robin
+to the ranks and rank 0 gathers the framebuffer over RCCL; total work is fixed ("strong").
+
+Prints ONE JSON line on rank 0 (contract in the task statement); see DESIGN.md "Measurement"
+for how roofline.achieved, roofline.traffic and cpu_baseline are defined.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy, same table
+
+
+def cpu_baseline(lights, spheres, tris, cam, W, H, depth, budget_s=20.0):
+    """The CPU oracle (a port of the reference's per-sample loop with its brute-force scene
+    scans, oracle/pt_oracle.cpp) timed on this box's host cores on a bounded window of the
+    same workload."""
+    import oracle
+    threads = os.cpu_count() or 1
+    win = (480, 320, 608, 384)                      # 128 x 64 window over the sphere's silhouette
+    t0 = time.perf_counter()
+    _, st = oracle.pt_render(lights, spheres, tris, cam, W, H, depth, 1, seed=1, window=win)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(64, budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    _, st = oracle.pt_render(lights, spheres, tris, cam, W, H, depth, spp, seed=1, window=win)
+    dt = time.perf_counter() - t0
+    samples = st["samples"]
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": "oracle/pt_oracle.cpp (reference per-sample loop, brute-force scan of all %d triangles), "
+                      "%dx%d window %s of the 1024x1024 image, %d spp, %d samples in %.1f s, OpenMP %d threads"
+                      % (len(tris), win[2] - win[0], win[3] - win[1], str(win), spp, samples, dt, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--tris", type=int, default=100_000)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r01_pmc_extend.json"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import path_tracing_amd as hpt
+    from path_tracing_amd import distributed, scene_io
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W = H = args.size
+    lights, spheres, tris = scene_io.cornell_with_sphere(args.tris)
+    cam = scene_io.make_camera(scene_io.CORNELL_EYE, scene_io.CORNELL_LOOK, scene_io.CORNELL_UP, 50.0, W, H)
+    scene = hpt.Scene(lights, spheres, tris)               # upload + BVH build: outside the timed region
+    stream = torch.cuda.current_stream().cuda_stream
+    base = dict(seed=1, rank=rank, world=world)
+    n_local = hpt.local_pixels(W, H, hpt.make_params(**base))
+    local = torch.zeros((n_local, 3), dtype=torch.float32, device="cuda")
+    image = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
+
+    def step(flags):
+        p = hpt.make_params(flags=flags, **base)
+
+        def render_local():
+            scene.render_pt_device(cam, W, H, args.depth, args.spp, p, local.data_ptr(), stream)
+            return local
+
+        def untile(gathered):
+            hpt.untile(gathered.data_ptr(), image.data_ptr(), W, H, hpt.make_params(**base), stream)
+            return image
+
+        return distributed.render_tiled(render_local, untile, rank, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(0)
+    fence()
+    t0 = time.perf_counter()
+    ext_ms, ext_n, tot_ms = 0.0, 0, 0.0
+    for _ in range(args.steps):
+        step(hpt.FLAG_TIME_KERNELS)        # HIP events around every launch, on the launch stream
+        st = scene.stats()                 # waits for this rank's render
+        ext_ms += st["ms_extend"]; ext_n += st["n_extend"]; tot_ms += st["ms_total"]
+        shade_ms, connect_ms, other_ms = st["ms_shade"], st["ms_connect"], st["ms_other"]
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # untimed pass that counts the work of the same render (boxes / triangles / rays per kernel)
+    step(hpt.FLAG_COUNT_WORK)
+    fence()
+    wc = scene.stats()
+
+    if rank == 0:
+        samples = W * H * args.spp
+        value = samples * args.steps / dt / 1e6
+        # dominant kernel: k_extend (closest-hit BVH traversal).  Algorithmic bytes per launch:
+        # 32 B per child box tested + 36 B per triangle tested + 44 B per ray (origin+direction
+        # in, queue index in, hit record out), DESIGN.md "Kernels".
+        ext_bytes = 32.0 * wc["boxes_closest"] + 36.0 * wc["tris_closest"] + 44.0 * wc["closest_rays"]
+        avg_launch_ms = ext_ms / max(ext_n, 1)
+        launches_per_render = ext_n / max(args.steps, 1)
+        bytes_per_launch = ext_bytes / max(launches_per_render, 1)
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        if os.path.exists(args.pmc_file):
+            try:
+                traffic = json.load(open(args.pmc_file)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        all_rays = wc["closest_rays"] + wc["shadow_rays"]
+        per_sample = (32.0 * (wc["boxes_closest"] + wc["boxes_shadow"]) + 36.0 * (wc["tris_closest"] + wc["tris_shadow"])
+                      + (28.0 + 128.0) * wc["path_iters"]) / max(wc["samples"], 1) + 12.0 / args.spp
+        out = {
+            "metric": "Msamples/s (paths/s) at 1024^2 x 256spp",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: unidirectional PT + NEE, Cornell-style box + tessellated sphere, "
+                                   "%d triangles behind a BVH, %dx%d, %d spp, depth %d, 1 cone light"
+                                   % (len(tris), W, H, args.spp, args.depth),
+                       "parallelism": "image tiles 32x32 round-robin over %d rank(s), RCCL gather to rank 0" % world,
+                       "seed": 1},
+            "roofline": {"bound": "hbm", "kernel": "k_extend (closest-hit BVH traversal)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_of_measured_copy_peak": achieved / HBM_ACHIEVABLE_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_render,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "rank 0's kernels; bytes = 32*boxes + 36*tris + 44*rays of this rank"},
+            "work": {"rays_per_sample": all_rays / max(wc["samples"], 1),
+                     "boxes_per_ray": (wc["boxes_closest"] + wc["boxes_shadow"]) / max(all_rays, 1),
+                     "tris_per_ray": (wc["tris_closest"] + wc["tris_shadow"]) / max(all_rays, 1),
+                     "algorithmic_bytes_per_sample": per_sample,
+                     "Mrays_per_s": all_rays * world / (dt / args.steps) / 1e6 if world == 1 else None,
+                     "device_ms_per_step_rank0": tot_ms / args.steps,
+                     "kernel_ms_last_step_rank0": {"extend": st["ms_extend"], "shade": shade_ms, "connect": connect_ms, "other": other_ms},
+                     "bvh_nodes": wc["bvh_nodes"], "bvh_depth": wc["bvh_depth"], "ms_bvh_build": wc["ms_bvh_build"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(lights, spheres, tris, cam, W, H, args.depth)
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

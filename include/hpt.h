@@ -73,8 +73,10 @@ typedef struct hpt_stats {
     uint64_t samples;         /* camera samples traced by the last render */
     uint64_t closest_rays;    /* closest-hit rays */
     uint64_t shadow_rays;     /* any-hit rays */
-    uint64_t boxes_tested;    /* child boxes slab-tested (2 per inner node visited); COUNT_WORK only */
-    uint64_t tris_tested;     /* triangle tests; COUNT_WORK only */
+    uint64_t boxes_closest;   /* child boxes slab-tested by closest-hit rays (2 per inner node); COUNT_WORK only */
+    uint64_t tris_closest;    /* triangle tests by closest-hit rays; COUNT_WORK only */
+    uint64_t boxes_shadow;    /* same, any-hit rays */
+    uint64_t tris_shadow;
     uint64_t path_iters;      /* (path, bounce) shading steps */
     double ms_total;          /* device time first-to-last kernel of the last render (HIP events) */
     double ms_extend, ms_shade, ms_connect, ms_other;   /* per-kernel-class sums; TIME_KERNELS only */

@@ -40,7 +40,8 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
-                ("boxes_tested", C.c_uint64), ("tris_tested", C.c_uint64), ("path_iters", C.c_uint64),
+                ("boxes_closest", C.c_uint64), ("tris_closest", C.c_uint64),
+                ("boxes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64), ("path_iters", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_shade", C.c_double),
                 ("ms_connect", C.c_double), ("ms_other", C.c_double),
                 ("n_extend", C.c_uint32), ("n_shade", C.c_uint32), ("n_connect", C.c_uint32), ("n_other", C.c_uint32),

@@ -53,7 +53,8 @@ struct hpt_scene {
     // workspace, grown on demand
     size_t cap_paths = 0, cap_local = 0;
     PathBuf pb{}; ShadowBuf sb{};
-    uint32_t *queue[2] = { nullptr, nullptr };
+    uint32_t *queue[2] = { nullptr, nullptr };   // path queues (ping-pong)
+    uint32_t *squeue = nullptr;                  // shadow queue (path slots)
     uint32_t *counters = nullptr; int n_counters = 0;
     float4 *accum = nullptr;
     WorkCounters *d_wc = nullptr;
@@ -72,8 +73,8 @@ namespace {
 void free_workspace(hpt_scene *s){
     hipFree(s->pb.org_eta); hipFree(s->pb.dir_flags); hipFree(s->pb.thr); hipFree(s->pb.col);
     hipFree(s->pb.rng); hipFree(s->pb.hit);
-    hipFree(s->sb.org_max); hipFree(s->sb.dir_path); hipFree(s->sb.contrib);
-    hipFree(s->queue[0]); hipFree(s->queue[1]);
+    hipFree(s->sb.org_max); hipFree(s->sb.dir); hipFree(s->sb.contrib);
+    hipFree(s->queue[0]); hipFree(s->queue[1]); hipFree(s->squeue); s->squeue = nullptr;
     s->pb = PathBuf{}; s->sb = ShadowBuf{}; s->queue[0] = s->queue[1] = nullptr; s->cap_paths = 0;
 }
 
@@ -87,10 +88,11 @@ int ensure_workspace(hpt_scene *s, size_t paths, size_t n_local, int n_counters)
         HIP_TRY(hipMalloc((void **) &s->pb.rng, paths * sizeof(uint2)));
         HIP_TRY(hipMalloc((void **) &s->pb.hit, paths * sizeof(uint2)));
         HIP_TRY(hipMalloc((void **) &s->sb.org_max, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &s->sb.dir_path, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &s->sb.dir, paths * sizeof(float4)));
         HIP_TRY(hipMalloc((void **) &s->sb.contrib, paths * sizeof(float4)));
         HIP_TRY(hipMalloc((void **) &s->queue[0], paths * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **) &s->queue[1], paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &s->squeue, paths * sizeof(uint32_t)));
         s->cap_paths = paths;
     }
     if(n_local > s->cap_local){
@@ -195,7 +197,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         uint32_t *qcnt = s->counters;                 // qcnt[i]: paths entering iteration i
         uint32_t *scnt = s->counters + (max_iters + 2);   // scnt[i]: shadow rays of iteration i
         { LaunchTimer t(s, stream, timek, 3);
-          launch_generate(stream, tl, cam, s->pb, s->queue[0], &qcnt[0], sthis,
+          launch_generate(stream, tl, cam, s->pb, &qcnt[0], sthis,
                           (uint32_t) (P.sample_offset + done), P.seed, wc); }
         int cur = 0;
         for(int it = 0; it < max_iters; ++it){
@@ -206,12 +208,12 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                 if(*s->h_count == 0u) break;
             }
             { LaunchTimer t(s, stream, timek, 0);
-              launch_extend(stream, s->sd, s->pb, s->queue[cur], &qcnt[it], slots, kflags, wc); }
+              launch_extend(stream, s->sd, s->pb, it == 0 ? nullptr : s->queue[cur], &qcnt[it], slots, kflags, wc); }
             { LaunchTimer t(s, stream, timek, 1);
-              launch_shade(stream, s->sd, s->pb, s->queue[cur], &qcnt[it], slots, s->queue[cur ^ 1], &qcnt[it + 1],
-                           s->sb, &scnt[it], eye_depth, P.max_delta, wc); }
+              launch_shade(stream, s->sd, s->pb, it == 0 ? nullptr : s->queue[cur], &qcnt[it], slots, s->queue[cur ^ 1],
+                           &qcnt[it + 1], s->sb, s->squeue, &scnt[it], eye_depth, P.max_delta, wc); }
             { LaunchTimer t(s, stream, timek, 2);
-              launch_connect(stream, s->sd, s->pb, s->sb, &scnt[it], slots, kflags, wc); }
+              launch_connect(stream, s->sd, s->pb, s->sb, s->squeue, &scnt[it], slots, kflags, wc); }
             cur ^= 1;
         }
         { LaunchTimer t(s, stream, timek, 3);
@@ -243,7 +245,8 @@ int collect_stats(hpt_scene *s){
     WorkCounters wc;
     HIP_TRY(hipMemcpy(&wc, s->d_wc, sizeof wc, hipMemcpyDeviceToHost));
     s->stats.samples = wc.samples; s->stats.closest_rays = wc.closest_rays; s->stats.shadow_rays = wc.shadow_rays;
-    s->stats.boxes_tested = wc.boxes; s->stats.tris_tested = wc.tris; s->stats.path_iters = wc.path_iters;
+    s->stats.boxes_closest = wc.boxes_closest; s->stats.tris_closest = wc.tris_closest;
+    s->stats.boxes_shadow = wc.boxes_shadow; s->stats.tris_shadow = wc.tris_shadow; s->stats.path_iters = wc.path_iters;
     s->stats_pending = false;
     return HPT_OK;
 }

@@ -25,10 +25,11 @@ struct PathBuf {
     uint2 *hit;          // extend result: as_uint(t) | primitive code
 };
 
-// Shadow-ray queue, structure of arrays indexed by queue position.
+// Pending shadow ray of a path, structure of arrays indexed by path slot (the shadow queue
+// itself is a compacted list of path slots).
 struct ShadowBuf {
     float4 *org_max;     // p1 xyz | max_d
-    float4 *dir_path;    // unit direction xyz | as_float(path slot)
+    float4 *dir;         // unit direction xyz | unused
     float4 *contrib;     // clamped contribution if unoccluded xyz | unused
 };
 
@@ -41,7 +42,7 @@ struct Tiling {
 struct CameraDev { float eye[3], UL[3], dx[3], dy[3]; };
 
 struct WorkCounters {    // device counters, COUNT_WORK only
-    unsigned long long boxes, tris, closest_rays, shadow_rays, path_iters, samples;
+    unsigned long long boxes_closest, tris_closest, boxes_shadow, tris_shadow, closest_rays, shadow_rays, path_iters, samples;
 };
 
 // primitive code in PathBuf::hit.y
@@ -50,16 +51,16 @@ constexpr uint32_t kHitRoundFlag = 0x80000000u;   // | index into rounds; else t
 
 constexpr int kBlock = 256;
 
-void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb, uint32_t *queue,
+void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb,
                      uint32_t *qcount, int samples_this_pass, uint32_t first_sample, uint64_t seed,
                      WorkCounters *wc);
 void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
                    uint32_t max_items, int flags, WorkCounters *wc);
 void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
-                  uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *scount,
-                  int max_depth, int max_delta, WorkCounters *wc);
-void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *scount,
-                    uint32_t max_items, int flags, WorkCounters *wc);
+                  uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue,
+                  uint32_t *scount, int max_depth, int max_delta, WorkCounters *wc);
+void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,
+                    const uint32_t *scount, uint32_t max_items, int flags, WorkCounters *wc);
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass);
 void launch_finalize(hipStream_t s, const Tiling &tl, const float4 *accum, float *d_local, float scale);
 void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, float *d_image);

@@ -42,6 +42,19 @@ HPT_DEV uint32_t wave_push(bool want, uint32_t *counter){
     return base + prefix;
 }
 
+// same prefix, reserving in a workgroup-local LDS counter
+HPT_DEV uint32_t lds_push(bool want, uint32_t *lds_counter){
+    unsigned long long mask = __ballot(want);
+    if(mask == 0ull) return 0u;
+    uint32_t lo = (uint32_t) mask, hi = (uint32_t) (mask >> 32);
+    uint32_t prefix = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    uint32_t base = 0u;
+    int leader = __ffsll((long long) mask) - 1;
+    if((int) (threadIdx.x & 63u) == leader) base = atomicAdd(lds_counter, (uint32_t) __popcll(mask));
+    base = (uint32_t) __shfl((int) base, leader, 64);
+    return base + prefix;
+}
+
 // ---- tiling -----------------------------------------------------------------------------
 // local slot p -> global pixel; false when the slot lies outside the image
 HPT_DEV bool tile_to_pixel(const Tiling &tl, uint32_t p, int &x, int &y){
@@ -193,8 +206,8 @@ HPT_DEV void flush_tally(const Tally &tally, uint32_t rays, WorkCounters *wc, bo
         b += __shfl_down(b, off, 64); t += __shfl_down(t, off, 64); r += __shfl_down(r, off, 64);
     }
     if((threadIdx.x & 63u) == 0u){
-        if(b) atomicAdd(&wc->boxes, b);
-        if(t) atomicAdd(&wc->tris, t);
+        if(b) atomicAdd(shadow ? &wc->boxes_shadow : &wc->boxes_closest, b);
+        if(t) atomicAdd(shadow ? &wc->tris_shadow : &wc->tris_closest, t);
         if(r) atomicAdd(shadow ? &wc->shadow_rays : &wc->closest_rays, r);
     }
 }
@@ -202,34 +215,33 @@ HPT_DEV void flush_tally(const Tally &tally, uint32_t rays, WorkCounters *wc, bo
 // ---- kernels ----------------------------------------------------------------------------
 
 __global__ __launch_bounds__(kBlock)
-void k_generate(Tiling tl, CameraDev cam, PathBuf pb, uint32_t *queue, uint32_t *qcount,
+void k_generate(Tiling tl, CameraDev cam, PathBuf pb, uint32_t *qcount,
                 uint32_t total, uint32_t first_sample, uint64_t seed, WorkCounters *wc){
+    // Slot i is path i: the first iteration's queue is the identity, so no compaction (and no
+    // atomics) here.  Slots outside the image are marked dead (flag bit 1) and never traced.
+    if(blockIdx.x == 0 && threadIdx.x == 0) *qcount = total;
     uint32_t stride = gridDim.x * kBlock;
-    uint32_t rounds = (total + stride - 1) / stride;
-    for(uint32_t it = 0; it < rounds; ++it){
-        uint32_t i = it * stride + blockIdx.x * kBlock + threadIdx.x;
-        bool active = false;
-        if(i < total){
-            uint32_t p = i % (uint32_t) tl.n_local, j = i / (uint32_t) tl.n_local;
-            int px, py;
-            active = tile_to_pixel(tl, p, px, py);
-            if(active){
-                uint64_t rs = rng_seed(seed, (uint32_t) (py * tl.W + px), first_sample + j);
-                float pixel_x = (float) px + rng_next(rs);
-                float pixel_y = (float) py + rng_next(rs);
-                f3 eye = mk3(cam.eye[0], cam.eye[1], cam.eye[2]);
-                f3 pixel_pos = mk3(cam.UL[0], cam.UL[1], cam.UL[2]) + mk3(cam.dx[0], cam.dx[1], cam.dx[2]) * pixel_x
-                               + mk3(cam.dy[0], cam.dy[1], cam.dy[2]) * pixel_y;
-                f3 dir = normalize3(pixel_pos - eye);
-                pb.org_eta[i] = make_float4(eye.x, eye.y, eye.z, 1.0f);
-                pb.dir_flags[i] = make_float4(dir.x, dir.y, dir.z, u2f(1u));      // last_is_delta = true, depth 0
-                pb.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-                pb.rng[i] = make_uint2((uint32_t) rs, (uint32_t) (rs >> 32));
-            }
-            pb.col[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += stride){
+        uint32_t p = i % (uint32_t) tl.n_local, j = i / (uint32_t) tl.n_local;
+        int px, py;
+        bool active = tile_to_pixel(tl, p, px, py);
+        if(active){
+            uint64_t rs = rng_seed(seed, (uint32_t) (py * tl.W + px), first_sample + j);
+            float pixel_x = (float) px + rng_next(rs);
+            float pixel_y = (float) py + rng_next(rs);
+            f3 eye = mk3(cam.eye[0], cam.eye[1], cam.eye[2]);
+            f3 pixel_pos = mk3(cam.UL[0], cam.UL[1], cam.UL[2]) + mk3(cam.dx[0], cam.dx[1], cam.dx[2]) * pixel_x
+                           + mk3(cam.dy[0], cam.dy[1], cam.dy[2]) * pixel_y;
+            f3 dir = normalize3(pixel_pos - eye);
+            pb.org_eta[i] = make_float4(eye.x, eye.y, eye.z, 1.0f);
+            pb.dir_flags[i] = make_float4(dir.x, dir.y, dir.z, u2f(1u));      // last_is_delta = true, depth 0
+            pb.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            pb.rng[i] = make_uint2((uint32_t) rs, (uint32_t) (rs >> 32));
+        } else {
+            pb.dir_flags[i] = make_float4(0.0f, 0.0f, 1.0f, u2f(2u));         // dead slot
+            pb.hit[i] = make_uint2(f2u(1e20f), kHitMiss);
         }
-        uint32_t pos = wave_push(active, qcount);
-        if(active) queue[pos] = i;
+        pb.col[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if(wc){
             unsigned long long m = __ballot(active);
             if((threadIdx.x & 63u) == 0u && m) atomicAdd(&wc->samples, (unsigned long long) __popcll(m));
@@ -246,8 +258,9 @@ void k_extend(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qc
     Tally tally; tally.boxes = 0; tally.tris = 0;
     uint32_t rays = 0;
     for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock){
-        uint32_t path = queue[i];
+        uint32_t path = queue ? queue[i] : i;              // null queue: identity (first iteration)
         float4 o = pb.org_eta[path], d = pb.dir_flags[path];
+        if(f2u(d.w) & 2u) continue;                        // slot outside the image
         float t; uint32_t prim;
         closest_hit<BRUTE, COUNT>(sc, xyz(o), xyz(d), stk, t, prim, tally);
         pb.hit[path] = make_uint2(f2u(t), prim);
@@ -258,19 +271,19 @@ void k_extend(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qc
 
 template <bool BRUTE, bool COUNT>
 __global__ __launch_bounds__(kBlock)
-void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *scount, WorkCounters *wc){
+void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue, const uint32_t *scount, WorkCounters *wc){
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     uint32_t count = *scount;
     uint32_t *stk = s_stack + threadIdx.x;
     Tally tally; tally.boxes = 0; tally.tris = 0;
     uint32_t rays = 0;
     for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock){
-        float4 a = sb.org_max[i], b = sb.dir_path[i];
+        uint32_t path = squeue[i];
+        float4 a = sb.org_max[path], b = sb.dir[path];
         bool vis = segment_visible<BRUTE, COUNT>(sc, xyz(a), xyz(b), a.w, stk, tally);
         ++rays;
         if(vis){
-            uint32_t path = f2u(b.w);
-            float4 c = sb.contrib[i];
+            float4 c = sb.contrib[path];
             float4 col = pb.col[path];
             col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
             pb.col[path] = col;
@@ -281,13 +294,22 @@ void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *scount, Wo
 
 constexpr int kLdsMats = 256;    // material records staged in LDS (8 KiB)
 constexpr int kLdsLights = 64;   // light records staged in LDS (5 KiB)
+constexpr int kShadeChunk = 2048;        // paths per workgroup at most (LDS staging capacity)
+constexpr int kShadeTargetGroups = 1024; // workgroups a short queue is spread over
 
 __global__ __launch_bounds__(kBlock)
 void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
-             uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *scount,
+             uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue, uint32_t *scount,
              int max_depth, int max_delta, WorkCounters *wc){
     __shared__ DevMaterial s_mats[kLdsMats];
     __shared__ DevLight s_lights[kLdsLights];
+    // survivors and shadow requests of this workgroup's chunk are compacted in LDS (wave64
+    // ballot + mbcnt prefix, one LDS atomic per wave) and flushed with ONE global atomic per
+    // queue: same-address global atomics saturate near 88 per microsecond on this chip.
+    __shared__ uint32_t s_next[kShadeChunk];
+    __shared__ uint32_t s_shadow[kShadeChunk];
+    __shared__ uint32_t s_cnt[4];          // [0] survivors, [1] shadow requests, [2],[3] global bases
+    if(threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
     const bool mats_in_lds = sc.num_mats <= kLdsMats;
     const bool lights_in_lds = sc.num_lights <= kLdsLights;
     if(mats_in_lds){
@@ -303,16 +325,21 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     const DevLight *lights = lights_in_lds ? s_lights : sc.lights;
 
     uint32_t count = *qcount;
-    uint32_t stride = gridDim.x * kBlock;
-    uint32_t rounds = (count + stride - 1) / stride;
+    // contiguous chunk per workgroup: small enough to spread a short queue over the chip,
+    // never larger than the LDS staging buffers
+    uint32_t chunk = (count + kShadeTargetGroups - 1) / kShadeTargetGroups;
+    chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+    chunk = chunk < (uint32_t) kBlock ? (uint32_t) kBlock : (chunk > (uint32_t) kShadeChunk ? (uint32_t) kShadeChunk : chunk);
+    uint32_t begin = blockIdx.x * chunk;
+    uint32_t end = begin + chunk < count ? begin + chunk : count;
     uint32_t iters = 0;
-    for(uint32_t it = 0; it < rounds; ++it){
-        uint32_t i = it * stride + blockIdx.x * kBlock + threadIdx.x;
+    for(uint32_t base = begin; base < end; base += kBlock){
+        uint32_t i = base + threadIdx.x;
         bool alive = false, want_shadow = false;
         uint32_t path = 0;
         f3 s_p1 = mk3(0, 0, 0), s_p2 = mk3(0, 0, 0), s_contrib = mk3(0, 0, 0);
         if(i < count){
-            path = queue[i];
+            path = queue ? queue[i] : i;
             ++iters;
             uint2 h = pb.hit[path];
             uint32_t prim = h.y;
@@ -472,18 +499,27 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                 }
             }
         }
-        uint32_t spos = wave_push(want_shadow, scount);
         if(want_shadow){
             f3 diff = s_p2 - s_p1;                          // geometric.cuh:298-303
             float dist = length3(diff);
             f3 dir = diff / dist;
-            sb.org_max[spos] = make_float4(s_p1.x, s_p1.y, s_p1.z, dist - 1e-3f);
-            sb.dir_path[spos] = make_float4(dir.x, dir.y, dir.z, u2f(path));
-            sb.contrib[spos] = make_float4(s_contrib.x, s_contrib.y, s_contrib.z, 0.0f);
+            sb.org_max[path] = make_float4(s_p1.x, s_p1.y, s_p1.z, dist - 1e-3f);
+            sb.dir[path] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            sb.contrib[path] = make_float4(s_contrib.x, s_contrib.y, s_contrib.z, 0.0f);
         }
-        uint32_t qpos = wave_push(alive, next_count);
-        if(alive) next_queue[qpos] = path;
+        uint32_t spos = lds_push(want_shadow, &s_cnt[1]);
+        if(want_shadow) s_shadow[spos] = path;
+        uint32_t qpos = lds_push(alive, &s_cnt[0]);
+        if(alive) s_next[qpos] = path;
     }
+    __syncthreads();
+    if(threadIdx.x == 0){
+        s_cnt[2] = s_cnt[0] ? atomicAdd(next_count, s_cnt[0]) : 0u;
+        s_cnt[3] = s_cnt[1] ? atomicAdd(scount, s_cnt[1]) : 0u;
+    }
+    __syncthreads();
+    for(uint32_t k = threadIdx.x; k < s_cnt[0]; k += kBlock) next_queue[s_cnt[2] + k] = s_next[k];
+    for(uint32_t k = threadIdx.x; k < s_cnt[1]; k += kBlock) squeue[s_cnt[3] + k] = s_shadow[k];
     if(wc){
         unsigned long long v = iters;
         for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -582,11 +618,11 @@ uint32_t grid_for(uint32_t items){
 
 // ---- launchers --------------------------------------------------------------------------
 
-void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb, uint32_t *queue,
+void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb,
                      uint32_t *qcount, int samples_this_pass, uint32_t first_sample, uint64_t seed,
                      WorkCounters *wc){
     uint32_t total = (uint32_t) tl.n_local * (uint32_t) samples_this_pass;
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(total)), dim3(kBlock), 0, s, tl, cam, pb, queue, qcount, total,
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(total)), dim3(kBlock), 0, s, tl, cam, pb, qcount, total,
                        first_sample, seed, wc);
 }
 
@@ -601,20 +637,25 @@ void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t
 }
 
 void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
-                  uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *scount,
-                  int max_depth, int max_delta, WorkCounters *wc){
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(max_items)), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
-                       next_count, sb, scount, max_depth, max_delta, wc);
+                  uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue,
+                  uint32_t *scount, int max_depth, int max_delta, WorkCounters *wc){
+    // enough workgroups for either chunking regime (see k_shade)
+    uint32_t g = (max_items + kShadeChunk - 1) / kShadeChunk;
+    if(g < (uint32_t) kShadeTargetGroups) g = (uint32_t) kShadeTargetGroups;
+    uint32_t small = (max_items + kBlock - 1) / kBlock;
+    if(small < g) g = small < 1u ? 1u : small;
+    hipLaunchKernelGGL(k_shade, dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
+                       next_count, sb, squeue, scount, max_depth, max_delta, wc);
 }
 
-void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *scount,
-                    uint32_t max_items, int flags, WorkCounters *wc){
+void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,
+                    const uint32_t *scount, uint32_t max_items, int flags, WorkCounters *wc){
     dim3 g(grid_for(max_items)), b(kBlock);
     bool brute = flags & 1, count = flags & 2;
-    if(brute && count) hipLaunchKernelGGL((k_connect<true, true>), g, b, 0, s, sc, pb, sb, scount, wc);
-    else if(brute) hipLaunchKernelGGL((k_connect<true, false>), g, b, 0, s, sc, pb, sb, scount, wc);
-    else if(count) hipLaunchKernelGGL((k_connect<false, true>), g, b, 0, s, sc, pb, sb, scount, wc);
-    else hipLaunchKernelGGL((k_connect<false, false>), g, b, 0, s, sc, pb, sb, scount, wc);
+    if(brute && count) hipLaunchKernelGGL((k_connect<true, true>), g, b, 0, s, sc, pb, sb, squeue, scount, wc);
+    else if(brute) hipLaunchKernelGGL((k_connect<true, false>), g, b, 0, s, sc, pb, sb, squeue, scount, wc);
+    else if(count) hipLaunchKernelGGL((k_connect<false, true>), g, b, 0, s, sc, pb, sb, squeue, scount, wc);
+    else hipLaunchKernelGGL((k_connect<false, false>), g, b, 0, s, sc, pb, sb, squeue, scount, wc);
 }
 
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass){

@@ -1,0 +1,52 @@
+"""Generates the committed golden vectors of tests/golden/ from the CPU oracle.
+
+Run from the repo root:  python tests/golden/make_golden.py
+Each .npz holds inputs' identity (scene name, size, seed, depth, spp) and the expected
+float32 image.  The oracle itself is pinned only as described in tests/golden/README.md.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from path_tracing_amd import scene_io as S  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def scene_arrays(name):
+    if name in ("input", "mis_test"):
+        sc = S.load_scene(os.path.join(HERE, "scenes", name + ".txt"))
+        return S.flatten_for_pt(sc), (sc.eye, sc.look_at, sc.view_up)
+    if name == "cornell_diffuse":
+        return S.cornell_diffuse(), (S.CORNELL_EYE, S.CORNELL_LOOK, S.CORNELL_UP)
+    if name == "cornell_sphere_2k":
+        return S.cornell_with_sphere(2000), (S.CORNELL_EYE, S.CORNELL_LOOK, S.CORNELL_UP)
+    raise KeyError(name)
+
+
+CASES = [  # name, W, H, depth, spp, seed
+    ("input", 64, 64, 4, 8, 7),
+    ("input", 50, 37, 4, 3, 11),
+    ("mis_test", 48, 48, 4, 4, 5),
+    ("cornell_diffuse", 64, 64, 4, 8, 2),
+    ("cornell_sphere_2k", 48, 48, 4, 4, 3),
+]
+
+
+def main():
+    for name, W, H, depth, spp, seed in CASES:
+        (L, sp, tr), (eye, look, up) = scene_arrays(name)
+        cam = S.make_camera(eye, look, up, 50.0, W, H)
+        img, st = oracle.pt_render(L, sp, tr, cam, W, H, depth, spp, seed=seed)
+        out = os.path.join(HERE, "pt_%s_%dx%d_d%d_%dspp_seed%d.npz" % (name, W, H, depth, spp, seed))
+        np.savez_compressed(out, image=img, scene=name, W=W, H=H, depth=depth, spp=spp, seed=seed,
+                            closest_rays=st["closest_rays"], shadow_rays=st["shadow_rays"])
+        print(out, img.mean(), st)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/hpt.h declares, and argument errors are reported through return codes (no GPU work)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hpt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hpt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(hpt):
+    lib = hpt.load_library()
+    names = _declared_symbols()
+    assert "hpt_render_pt" in names and "hpt_pt_render_wrapper" in names and len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), "libhpt.so does not export %s" % n
+
+
+def test_params_struct_matches_header(hpt):
+    assert C.sizeof(hpt.Params) == 40
+    assert hpt.Stats.ms_total.offset == 64 and hpt.Stats.bvh_nodes.offset == 120
+
+
+def test_local_pixels_and_tiling_rules(hpt):
+    p = hpt.make_params(world=1)
+    assert hpt.local_pixels(1024, 1024, p) == 1024 * 1024
+    assert hpt.local_pixels(50, 37, p) == 2 * 2 * 32 * 32
+    p8 = hpt.make_params(world=8, rank=3)
+    assert hpt.local_pixels(1024, 1024, p8) == 1024 * 1024 // 8
+    p3 = hpt.make_params(world=3, rank=2, tile=16)
+    assert hpt.local_pixels(100, 60, p3) == ((7 * 4 + 2) // 3) * 256
+    bad = hpt.make_params(tile=12)
+    lib = hpt.load_library()
+    assert lib.hpt_local_pixels(64, 64, C.byref(bad)) == -1
+    assert b"multiple of 8" in lib.hpt_last_error()
+    bad = hpt.make_params(world=2, rank=2)
+    assert lib.hpt_local_pixels(64, 64, C.byref(bad)) == -1
+
+
+def test_argument_errors_are_return_codes(hpt):
+    lib = hpt.load_library()
+    assert lib.hpt_scene_create(None, 0, None, 0, None, 3, C.byref(C.c_void_p())) != 0
+    assert b"null primitive array" in lib.hpt_last_error()
+    assert lib.hpt_scene_create(None, -1, None, 0, None, 0, C.byref(C.c_void_p())) != 0
+    assert lib.hpt_render_pt(None, None, 8, 8, 4, 1, None, None) != 0
+    assert lib.hpt_get_stats(None, None) != 0
+    lib.hpt_scene_destroy(None)     # no-op, like free(NULL)
+
+
+def test_host_tiling_mirror_roundtrip():
+    from path_tracing_amd import tiling
+    rng = np.random.default_rng(0)
+    for (W, H, tile, world) in ((50, 37, 32, 1), (64, 64, 8, 4), (100, 60, 16, 3), (33, 9, 8, 8)):
+        img = rng.random((H, W, 3)).astype(np.float32)
+        locs = np.stack([tiling.tile_image(img, tile, r, world) for r in range(world)])
+        assert locs.shape[1] == tiling.tiling_dims(W, H, tile, world)[3]
+        back = tiling.untile_image(locs, W, H, tile, world)
+        assert np.array_equal(back, img)
+        # every pixel belongs to exactly one rank
+        cover = np.zeros((H, W), np.int32)
+        for r in range(world):
+            x, y, v = tiling.local_to_pixel(W, H, tile, r, world)
+            np.add.at(cover, (y[v], x[v]), 1)
+        assert (cover == 1).all()
