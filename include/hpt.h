@@ -83,6 +83,10 @@ typedef struct hpt_stats {
     uint32_t n_extend, n_shade, n_connect, n_other;     /* launches per class */
     uint32_t bvh_nodes, bvh_depth, n_tris, n_materials;
     double ms_bvh_build, ms_upload;
+    /* SIMD efficiency of the traversal loops (COUNT_WORK only): lane_steps = loop trips summed over
+     * lanes, wave_steps = 64 x the longest lane's trips summed over the wave's rays */
+    uint64_t lane_steps_closest, wave_steps_closest, lane_steps_shadow, wave_steps_shadow;   /* inner-node trips */
+    uint64_t leaf_lane_closest, leaf_wave_closest, leaf_lane_shadow, leaf_wave_shadow;       /* leaf trips */
 } hpt_stats;
 
 const char *hpt_last_error(void);

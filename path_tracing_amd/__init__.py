@@ -46,7 +46,11 @@ class Stats(C.Structure):
                 ("ms_connect", C.c_double), ("ms_other", C.c_double),
                 ("n_extend", C.c_uint32), ("n_shade", C.c_uint32), ("n_connect", C.c_uint32), ("n_other", C.c_uint32),
                 ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("n_tris", C.c_uint32), ("n_materials", C.c_uint32),
-                ("ms_bvh_build", C.c_double), ("ms_upload", C.c_double)]
+                ("ms_bvh_build", C.c_double), ("ms_upload", C.c_double),
+                ("lane_steps_closest", C.c_uint64), ("wave_steps_closest", C.c_uint64),
+                ("lane_steps_shadow", C.c_uint64), ("wave_steps_shadow", C.c_uint64),
+                ("leaf_lane_closest", C.c_uint64), ("leaf_wave_closest", C.c_uint64),
+                ("leaf_lane_shadow", C.c_uint64), ("leaf_wave_shadow", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -49,6 +49,8 @@ struct hpt_scene {
     BvhNode *d_nodes = nullptr; DevTriangle *d_tris = nullptr; DevRound *d_rounds = nullptr;
     DevMaterial *d_mats = nullptr; DevLight *d_lights = nullptr;
     int device = 0;
+    int stack_levels = kStackDepth;       // traversal stack entries per lane
+    int num_cus = 256;
 
     // workspace, grown on demand
     size_t cap_paths = 0, cap_local = 0;
@@ -179,7 +181,8 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     const int flags = P.flags;
     const bool count = (flags & HPT_FLAG_COUNT_WORK) != 0;
     const bool timek = (flags & HPT_FLAG_TIME_KERNELS) != 0;
-    const int kflags = (flags & HPT_FLAG_BRUTE_FORCE ? 1 : 0) | (count ? 2 : 0);
+    const bool brute = (flags & HPT_FLAG_BRUTE_FORCE) != 0;
+    const int kflags = (brute ? 1 : 0) | (count ? 2 : 0);
     WorkCounters *wc = count ? s->d_wc : nullptr;
     s->timed.clear(); s->event_next = 0;
     s->last_flags = flags;
@@ -200,6 +203,8 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
           launch_generate(stream, tl, cam, s->pb, &qcnt[0], sthis,
                           (uint32_t) (P.sample_offset + done), P.seed, wc); }
         int cur = 0;
+        const bool legacy = brute || (P.reserved & 1);      // separate extend/connect kernels (the scan variants)
+        int pending_shadow = -1;                            // iteration whose shadow queue is not traced yet
         for(int it = 0; it < max_iters; ++it){
             if(it >= eye_depth){
                 // only free delta bounces can keep a path alive this long: look before launching
@@ -207,14 +212,30 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                 HIP_TRY(hipStreamSynchronize(stream));
                 if(*s->h_count == 0u) break;
             }
-            { LaunchTimer t(s, stream, timek, 0);
-              launch_extend(stream, s->sd, s->pb, it == 0 ? nullptr : s->queue[cur], &qcnt[it], slots, kflags, wc); }
+            const uint32_t *eq = it == 0 ? nullptr : s->queue[cur];
+            if(legacy){
+                { LaunchTimer t(s, stream, timek, 0);
+                  launch_extend(stream, s->sd, s->pb, eq, &qcnt[it], slots, kflags, wc); }
+            } else {
+                // extension rays of this iteration + shadow rays of the previous one, one launch
+                LaunchTimer t(s, stream, timek, 0);
+                launch_trace(stream, s->sd, s->pb, s->sb, eq, &qcnt[it], slots, s->squeue,
+                             pending_shadow >= 0 ? &scnt[pending_shadow] : nullptr, slots, s->stack_levels, kflags, P.reserved, wc);
+                pending_shadow = -1;
+            }
             { LaunchTimer t(s, stream, timek, 1);
-              launch_shade(stream, s->sd, s->pb, it == 0 ? nullptr : s->queue[cur], &qcnt[it], slots, s->queue[cur ^ 1],
+              launch_shade(stream, s->sd, s->pb, eq, &qcnt[it], slots, s->queue[cur ^ 1],
                            &qcnt[it + 1], s->sb, s->squeue, &scnt[it], eye_depth, P.max_delta, wc); }
-            { LaunchTimer t(s, stream, timek, 2);
-              launch_connect(stream, s->sd, s->pb, s->sb, s->squeue, &scnt[it], slots, kflags, wc); }
+            if(legacy){
+                LaunchTimer t(s, stream, timek, 2);
+                launch_connect(stream, s->sd, s->pb, s->sb, s->squeue, &scnt[it], slots, kflags, wc);
+            } else pending_shadow = it;
             cur ^= 1;
+        }
+        if(pending_shadow >= 0){
+            LaunchTimer t(s, stream, timek, 2);
+            launch_trace(stream, s->sd, s->pb, s->sb, nullptr, nullptr, 0, s->squeue, &scnt[pending_shadow], slots,
+                         s->stack_levels, kflags, P.reserved, wc);
         }
         { LaunchTimer t(s, stream, timek, 3);
           launch_resolve(stream, tl, s->pb, s->accum, sthis); }
@@ -247,6 +268,10 @@ int collect_stats(hpt_scene *s){
     s->stats.samples = wc.samples; s->stats.closest_rays = wc.closest_rays; s->stats.shadow_rays = wc.shadow_rays;
     s->stats.boxes_closest = wc.boxes_closest; s->stats.tris_closest = wc.tris_closest;
     s->stats.boxes_shadow = wc.boxes_shadow; s->stats.tris_shadow = wc.tris_shadow; s->stats.path_iters = wc.path_iters;
+    s->stats.lane_steps_closest = wc.lane_steps_closest; s->stats.wave_steps_closest = wc.wave_steps_closest;
+    s->stats.lane_steps_shadow = wc.lane_steps_shadow; s->stats.wave_steps_shadow = wc.wave_steps_shadow;
+    s->stats.leaf_lane_closest = wc.leaf_lane_closest; s->stats.leaf_wave_closest = wc.leaf_wave_closest;
+    s->stats.leaf_lane_shadow = wc.leaf_lane_shadow; s->stats.leaf_wave_shadow = wc.leaf_wave_shadow;
     s->stats_pending = false;
     return HPT_OK;
 }
@@ -273,6 +298,7 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
     hpt_scene *s = new hpt_scene();
     auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipGetDevice(&s->device);
+    if(e == hipSuccess){ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount; }
     if(e == hipSuccess) e = upload(hs.nodes, &s->d_nodes);
     if(e == hipSuccess) e = upload(hs.tris, &s->d_tris);
     if(e == hipSuccess) e = upload(hs.rounds, &s->d_rounds);
@@ -290,6 +316,7 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
     s->sd.num_mats = (int) hs.materials.size(); s->sd.pad = 0;
     memset(&s->stats, 0, sizeof s->stats);
     s->stats.bvh_nodes = (uint32_t) hs.nodes.size(); s->stats.bvh_depth = (uint32_t) hs.bvh_depth;
+    s->stack_levels = hs.bvh_depth > 0 ? hs.bvh_depth : 1;     // a leaf at depth d has d inner ancestors: at most d pushes
     s->stats.n_tris = (uint32_t) nt; s->stats.n_materials = (uint32_t) hs.materials.size();
     s->stats.ms_bvh_build = hs.ms_bvh_build;
     s->stats.ms_upload = std::chrono::duration<double, std::milli>(t1 - t0).count();

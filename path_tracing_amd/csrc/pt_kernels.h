@@ -42,7 +42,9 @@ struct Tiling {
 struct CameraDev { float eye[3], UL[3], dx[3], dy[3]; };
 
 struct WorkCounters {    // device counters, COUNT_WORK only
-    unsigned long long boxes_closest, tris_closest, boxes_shadow, tris_shadow, closest_rays, shadow_rays, path_iters, samples;
+    unsigned long long boxes_closest, tris_closest, boxes_shadow, tris_shadow, closest_rays, shadow_rays, path_iters, samples,
+                       lane_steps_closest, wave_steps_closest, lane_steps_shadow, wave_steps_shadow,
+                       leaf_lane_closest, leaf_wave_closest, leaf_lane_shadow, leaf_wave_shadow;
 };
 
 // primitive code in PathBuf::hit.y
@@ -61,6 +63,10 @@ void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t 
                   uint32_t *scount, int max_depth, int max_delta, WorkCounters *wc);
 void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,
                     const uint32_t *scount, uint32_t max_items, int flags, WorkCounters *wc);
+// merged closest-hit (equeue) + any-hit (squeue) launch; either queue may be absent (null count)
+void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue,
+                  const uint32_t *ecount, uint32_t max_extend, const uint32_t *squeue, const uint32_t *scount,
+                  uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc);
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass);
 void launch_finalize(hipStream_t s, const Tiling &tl, const float4 *accum, float *d_local, float scale);
 void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, float *d_image);

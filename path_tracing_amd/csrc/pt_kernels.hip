@@ -72,7 +72,8 @@ HPT_DEV bool tile_to_pixel(const Tiling &tl, uint32_t p, int &x, int &y){
 }
 
 // ---- traversal --------------------------------------------------------------------------
-struct Tally { uint32_t boxes, tris; };
+struct Tally { uint32_t boxes, tris, steps, wave_steps; };   // steps: traversal loop trips of this lane;
+                                                              // wave_steps: per ray, the wave's longest lane
 
 // Walks the triangle BVH.  ANY: returns true at the first opaque blocker in (1e-3, tmax).
 // Closest: refines (best_t, best_slot, best_ord); exact ties go to the lower scan ordinal,
@@ -90,6 +91,7 @@ HPT_DEV bool walk_bvh(const SceneDev &sc, f3 ro, f3 rd, float tmax, uint32_t *st
     int sp = 0;
     for(;;){
         bool descend = false;
+        if(COUNT) tally.steps += 1;
         if(!(cur & kLeafFlag)){
             const float4 *n = sc.nodes + (size_t) cur * 4;
             float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
@@ -199,13 +201,21 @@ HPT_DEV bool segment_visible(const SceneDev &sc, f3 p1, f3 dir, float max_d, uin
     return !blocked;
 }
 
+HPT_DEV uint32_t wave_max_u32(uint32_t v){
+    for(int off = 32; off > 0; off >>= 1){ uint32_t o = (uint32_t) __shfl_xor((int) v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
 HPT_DEV void flush_tally(const Tally &tally, uint32_t rays, WorkCounters *wc, bool shadow){
     // wave reduction, then one atomic per wave and counter
-    unsigned long long b = tally.boxes, t = tally.tris, r = rays;
+    unsigned long long b = tally.boxes, t = tally.tris, r = rays, st = tally.steps;
     for(int off = 32; off > 0; off >>= 1){
         b += __shfl_down(b, off, 64); t += __shfl_down(t, off, 64); r += __shfl_down(r, off, 64);
+        st += __shfl_down(st, off, 64);
     }
     if((threadIdx.x & 63u) == 0u){
+        if(st) atomicAdd(shadow ? &wc->lane_steps_shadow : &wc->lane_steps_closest, st);
+        if(tally.wave_steps) atomicAdd(shadow ? &wc->wave_steps_shadow : &wc->wave_steps_closest, 64ull * tally.wave_steps);
         if(b) atomicAdd(shadow ? &wc->boxes_shadow : &wc->boxes_closest, b);
         if(t) atomicAdd(shadow ? &wc->tris_shadow : &wc->tris_closest, t);
         if(r) atomicAdd(shadow ? &wc->shadow_rays : &wc->closest_rays, r);
@@ -255,16 +265,18 @@ void k_extend(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qc
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     uint32_t count = *qcount;
     uint32_t *stk = s_stack + threadIdx.x;
-    Tally tally; tally.boxes = 0; tally.tris = 0;
+    Tally tally; tally.boxes = 0; tally.tris = 0; tally.steps = 0; tally.wave_steps = 0;
     uint32_t rays = 0;
     for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock){
         uint32_t path = queue ? queue[i] : i;              // null queue: identity (first iteration)
         float4 o = pb.org_eta[path], d = pb.dir_flags[path];
         if(f2u(d.w) & 2u) continue;                        // slot outside the image
         float t; uint32_t prim;
+        uint32_t s0 = tally.steps;
         closest_hit<BRUTE, COUNT>(sc, xyz(o), xyz(d), stk, t, prim, tally);
         pb.hit[path] = make_uint2(f2u(t), prim);
         ++rays;
+        if(COUNT) tally.wave_steps += wave_max_u32(tally.steps - s0);     // lanes that skipped the trip are not here
     }
     if(COUNT) flush_tally(tally, rays, wc, false);
 }
@@ -275,13 +287,15 @@ void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue, co
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     uint32_t count = *scount;
     uint32_t *stk = s_stack + threadIdx.x;
-    Tally tally; tally.boxes = 0; tally.tris = 0;
+    Tally tally; tally.boxes = 0; tally.tris = 0; tally.steps = 0; tally.wave_steps = 0;
     uint32_t rays = 0;
     for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock){
         uint32_t path = squeue[i];
         float4 a = sb.org_max[path], b = sb.dir[path];
+        uint32_t s0 = tally.steps;
         bool vis = segment_visible<BRUTE, COUNT>(sc, xyz(a), xyz(b), a.w, stk, tally);
         ++rays;
+        if(COUNT) tally.wave_steps += wave_max_u32(tally.steps - s0);
         if(vis){
             float4 c = sb.contrib[path];
             float4 col = pb.col[path];
@@ -576,13 +590,226 @@ void k_untile(Tiling tl, const float *gathered, float *image){
     image[dst + 2] = gathered[src + 2];
 }
 
+// ---- merged trace kernel: closest-hit and any-hit rays with dynamic lane refill -----------
+// One launch serves the extension rays of iteration i+1 and the shadow rays of iteration i
+// (they are independent).  A workgroup owns a contiguous chunk of one queue; its lanes pull
+// rays from the chunk through an LDS counter, and a lane whose ray is finished pulls the next
+// one as soon as enough lanes of its wave are idle.  Inside, the classic while-while shape:
+// lanes walk inner nodes until each holds a leaf, then the (much longer) triangle code runs
+// once for all of them.
+//
+// Measured alternatives on config 3 (1024^2, 32 spp, ms per render; this version 42.3):
+//   one ray per lane, separate extend/connect launches, 32 KiB static stack ........ 69.5
+//   single loop doing a node OR a leaf step per trip (both code paths every trip) ... 45.5
+//   per-trip vote between refill / node step / leaf step ............................. 44.4
+//   persistent waves pulling 256-ray batches from one global cursor .................. 55.9
+//   persistent waves, 64-ray batches, 32 cursors on ONE 128-B line ................... 207.9
+//   same with one cursor per 128-B line (82 VGPRs) ................................... 47.5
+// Chunk size: 256 -> 47.3, 512 -> 45.5, 1024 -> 49.6, 2048 -> 59.3 (long chunks leave the tail of
+// a launch to a few workgroups); refill threshold 8 -> 51.0, 16 -> 49.6, 32 -> 48.6, 48 -> 48.0.
+constexpr int kTraceChunk = 512;      // rays per workgroup
+constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
+
+template <bool ANY, bool COUNT>
+HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *queue,
+                         uint32_t end, uint32_t *stk, uint32_t *s_next, int refill_min, WorkCounters *wc){
+    bool active = false, exhausted = false;
+    uint32_t path = 0u, cur = 0u;
+    int sp = 0;
+    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+    float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
+    float tmax = 0.0f, limit = 0.0f, best_t = 1e20f;
+    uint32_t best_prim = kHitMiss, best_ord = 0xFFFFFFFFu;
+    unsigned long long n_lane_steps = 0, n_wave_steps = 0, n_boxes = 0, n_tris = 0, n_rays = 0, n_leaf_lane = 0, n_leaf_wave = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    for(;;){
+        unsigned long long idle = __ballot(!active);
+        if(idle != 0ull && !exhausted && (idle == ~0ull || __popcll(idle) >= refill_min)){
+            // ---- refill: idle lanes pull the next rays of this workgroup's chunk ----
+            uint32_t n = (uint32_t) __popcll(idle);
+            uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+            int leader = __ffsll((long long) idle) - 1;
+            uint32_t base = 0u;
+            if((int) lane == leader) base = atomicAdd(s_next, n);
+            base = (uint32_t) __shfl((int) base, leader, 64);
+            exhausted = base + n >= end;
+            if(!active){
+                uint32_t i = base + prefix;
+                if(i < end){
+                    path = queue ? queue[i] : i;
+                    bool start = true;
+                    if(ANY){
+                        float4 a = sb.org_max[path], b = sb.dir[path];
+                        ro = xyz(a); rd = xyz(b); tmax = a.w;
+                        if(COUNT) n_rays += 1;
+                        // spheres first (the reference scans them after the triangles; the result is a boolean)
+                        for(int r = 0; r < sc.num_spheres; ++r){
+                            DevRound rr = sc.rounds[r];
+                            float t;
+                            if(hit_sphere(ro, rd, mk3(rr.c[0], rr.c[1], rr.c[2]), rr.r, tmax, t) && t > 1e-3f && (rr.flags & 1u)) start = false;
+                        }
+                        limit = tmax;
+                    } else {
+                        float4 o = pb.org_eta[path], d = pb.dir_flags[path];
+                        ro = xyz(o); rd = xyz(d);
+                        if(f2u(d.w) & 2u) start = false;                    // slot outside the image
+                        else {
+                            if(COUNT) n_rays += 1;
+                            best_t = 1e20f; best_prim = kHitMiss; best_ord = 0xFFFFFFFFu;
+                            for(int r = 0; r < sc.num_rounds; ++r){
+                                DevRound rr = sc.rounds[r];
+                                float t;
+                                if(hit_sphere(ro, rd, mk3(rr.c[0], rr.c[1], rr.c[2]), rr.r, 1e20f, t) && t < best_t){
+                                    best_t = t; best_prim = kHitRoundFlag | (uint32_t) r; best_ord = (uint32_t) r;
+                                }
+                            }
+                            limit = best_t;
+                        }
+                    }
+                    if(start){
+                        float dx = fabsf(rd.x) > 1e-20f ? rd.x : copysignf(1e-20f, rd.x);
+                        float dy = fabsf(rd.y) > 1e-20f ? rd.y : copysignf(1e-20f, rd.y);
+                        float dz = fabsf(rd.z) > 1e-20f ? rd.z : copysignf(1e-20f, rd.z);
+                        ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+                        ox = ro.x * ix; oy = ro.y * iy; oz = ro.z * iz;
+                        cur = 0u; sp = 0;
+                        active = true;
+                    }
+                }
+            }
+            if(!__any(active)){
+                if(exhausted) break;
+                continue;
+            }
+        } else if(idle == ~0ull){
+            break;                                      // chunk exhausted and every ray finished
+        }
+        // phase 1: walk inner nodes until this lane holds a leaf (or its ray is finished)
+        while(active && !(cur & kLeafFlag)){
+            if(COUNT){
+                n_lane_steps += 1; n_boxes += 2;
+                if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_wave_steps += 64;   // one wave trip
+            }
+            const float4 *n = sc.nodes + (size_t) cur * 4;
+            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            float a0 = fmaf(n0.x, ix, -ox), a1 = fmaf(n1.x, ix, -ox);
+            float b0 = fmaf(n0.y, iy, -oy), b1 = fmaf(n1.y, iy, -oy);
+            float c0 = fmaf(n0.z, iz, -oz), c1 = fmaf(n1.z, iz, -oz);
+            float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+            float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
+            a0 = fmaf(n2.x, ix, -ox); a1 = fmaf(n3.x, ix, -ox);
+            b0 = fmaf(n2.y, iy, -oy); b1 = fmaf(n3.y, iy, -oy);
+            c0 = fmaf(n2.z, iz, -oz); c1 = fmaf(n3.z, iz, -oz);
+            float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+            float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
+            uint32_t lc = f2u(n0.w), rc = f2u(n1.w);
+            bool hl = (ln <= lf * 1.000002f) && (lc != kEmptyChild);
+            bool hr = (rn <= rf * 1.000002f) && (rc != kEmptyChild);
+            if(hl && hr){
+                bool left_first = ln <= rn;
+                stk[sp * kBlock] = left_first ? rc : lc;
+                ++sp;
+                cur = left_first ? lc : rc;
+            } else if(hl) cur = lc;
+            else if(hr) cur = rc;
+            else if(sp > 0){ --sp; cur = stk[sp * kBlock]; }
+            else {
+                active = false;                                   // stack empty: ray finished
+                if(!ANY) pb.hit[path] = make_uint2(f2u(best_t), best_prim);
+                else {
+                    float4 c = sb.contrib[path];
+                    float4 col = pb.col[path];
+                    col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
+                    pb.col[path] = col;
+                }
+            }
+        }
+        // phase 2: the leaf
+        if(active){
+            if(COUNT){
+                n_leaf_lane += 1;
+                if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_leaf_wave += 64;
+            }
+            bool blocked = false;
+            uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
+            uint32_t cnt = (cur & 7u) + 1u;
+            for(uint32_t k = 0; k < cnt; ++k){
+                const float4 *tp = sc.tris + (size_t) (first + k) * 3;
+                float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                if(COUNT) n_tris += 1;
+                float t;
+                if(hit_triangle(ro, rd, xyz(t0), xyz(t1), xyz(t2), ANY ? tmax : 1e20f, t)){
+                    if(ANY){
+                        if(t > 1e-3f && (f2u(t2.w) & 1u)) blocked = true;
+                    } else {
+                        uint32_t ord = f2u(t0.w);
+                        if(t < best_t || (t == best_t && ord < best_ord)){
+                            best_t = t; best_prim = first + k; best_ord = ord; limit = t;
+                        }
+                    }
+                }
+            }
+            if(ANY && blocked) active = false;                    // occluded: no contribution
+            else if(sp > 0){ --sp; cur = stk[sp * kBlock]; }
+            else {
+                active = false;
+                if(!ANY) pb.hit[path] = make_uint2(f2u(best_t), best_prim);
+                else {
+                    float4 c = sb.contrib[path];
+                    float4 col = pb.col[path];
+                    col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
+                    pb.col[path] = col;
+                }
+            }
+        }
+    }
+    if(COUNT){
+        for(int off = 32; off > 0; off >>= 1){
+            n_boxes += __shfl_down(n_boxes, off, 64); n_tris += __shfl_down(n_tris, off, 64);
+            n_rays += __shfl_down(n_rays, off, 64); n_lane_steps += __shfl_down(n_lane_steps, off, 64);
+            n_wave_steps += __shfl_down(n_wave_steps, off, 64); n_leaf_lane += __shfl_down(n_leaf_lane, off, 64);
+            n_leaf_wave += __shfl_down(n_leaf_wave, off, 64);
+        }
+        if(lane == 0u){
+            if(n_boxes) atomicAdd(ANY ? &wc->boxes_shadow : &wc->boxes_closest, n_boxes);
+            if(n_tris) atomicAdd(ANY ? &wc->tris_shadow : &wc->tris_closest, n_tris);
+            if(n_rays) atomicAdd(ANY ? &wc->shadow_rays : &wc->closest_rays, n_rays);
+            if(n_lane_steps) atomicAdd(ANY ? &wc->lane_steps_shadow : &wc->lane_steps_closest, n_lane_steps);
+            if(n_wave_steps) atomicAdd(ANY ? &wc->wave_steps_shadow : &wc->wave_steps_closest, n_wave_steps);
+            if(n_leaf_lane) atomicAdd(ANY ? &wc->leaf_lane_shadow : &wc->leaf_lane_closest, n_leaf_lane);
+            if(n_leaf_wave) atomicAdd(ANY ? &wc->leaf_wave_shadow : &wc->leaf_wave_closest, n_leaf_wave);
+        }
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock)
+void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, const uint32_t *ecount_ptr,
+             const uint32_t *squeue, const uint32_t *scount_ptr, uint32_t chunk_rays, int refill_min, WorkCounters *wc){
+    extern __shared__ uint32_t s_dyn_stack[];        // [stack level][lane], sized by the BVH depth
+    __shared__ uint32_t s_next;
+    uint32_t ecount = ecount_ptr ? *ecount_ptr : 0u, scount = scount_ptr ? *scount_ptr : 0u;
+    uint32_t ne = (ecount + chunk_rays - 1) / chunk_rays, ns = (scount + chunk_rays - 1) / chunk_rays;
+    uint32_t bid = blockIdx.x;
+    if(bid >= ne + ns) return;
+    bool shadow = bid >= ne;
+    uint32_t chunk = shadow ? bid - ne : bid;
+    uint32_t begin = chunk * chunk_rays;
+    uint32_t total = shadow ? scount : ecount;
+    uint32_t end = begin + chunk_rays < total ? begin + chunk_rays : total;
+    if(threadIdx.x == 0) s_next = begin;
+    __syncthreads();
+    if(shadow) trace_chunk<true, COUNT>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, wc);
+    else trace_chunk<false, COUNT>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, wc);
+}
+
 template <bool BRUTE>
 __global__ __launch_bounds__(kBlock)
 void k_probe_closest(SceneDev sc, const float *org, const float *dir, int n, float *t_out, int32_t *prim_out){
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     int i = blockIdx.x * kBlock + threadIdx.x;
     if(i >= n) return;
-    Tally tally; tally.boxes = 0; tally.tris = 0;
+    Tally tally; tally.boxes = 0; tally.tris = 0; tally.steps = 0; tally.wave_steps = 0;
     float t; uint32_t prim;
     closest_hit<BRUTE, false>(sc, mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
                               s_stack + threadIdx.x, t, prim, tally);
@@ -600,7 +827,7 @@ void k_probe_visibility(SceneDev sc, const float *p1, const float *p2, int n, in
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     int i = blockIdx.x * kBlock + threadIdx.x;
     if(i >= n) return;
-    Tally tally; tally.boxes = 0; tally.tris = 0;
+    Tally tally; tally.boxes = 0; tally.tris = 0; tally.steps = 0; tally.wave_steps = 0;
     f3 a = mk3(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]), b = mk3(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]);
     f3 diff = b - a;
     float dist = length3(diff);
@@ -656,6 +883,20 @@ void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb,
     else if(brute) hipLaunchKernelGGL((k_connect<true, false>), g, b, 0, s, sc, pb, sb, squeue, scount, wc);
     else if(count) hipLaunchKernelGGL((k_connect<false, true>), g, b, 0, s, sc, pb, sb, squeue, scount, wc);
     else hipLaunchKernelGGL((k_connect<false, false>), g, b, 0, s, sc, pb, sb, squeue, scount, wc);
+}
+
+void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue,
+                  const uint32_t *ecount, uint32_t max_extend, const uint32_t *squeue, const uint32_t *scount,
+                  uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc){
+    uint32_t chunk = ((tuning >> 16) & 0xFF) ? (uint32_t) ((tuning >> 16) & 0xFF) * 256u : (uint32_t) kTraceChunk;
+    int refill_min = ((tuning >> 8) & 0xFF) ? ((tuning >> 8) & 0xFF) : kRefillMin;
+    uint32_t g = (ecount ? (max_extend + chunk - 1) / chunk : 0u) + (scount ? (max_shadow + chunk - 1) / chunk : 0u);
+    if(g == 0u) return;
+    if(stack_levels < 1) stack_levels = 1;
+    if(stack_levels > kStackDepth) stack_levels = kStackDepth;
+    size_t lds = (size_t) stack_levels * kBlock * sizeof(uint32_t);
+    if(flags & 2) hipLaunchKernelGGL((k_trace<true>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, wc);
+    else hipLaunchKernelGGL((k_trace<false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, wc);
 }
 
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass){

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <array>
@@ -51,6 +52,7 @@ struct Builder {
     std::vector<uint32_t> order;      // leaf-order list of input triangle indices
     float pad_abs = 0.0f;
     int max_depth_seen = 0;
+    int max_leaf = kMaxLeafTris;
 
     static constexpr int kBins = 16;
 
@@ -78,12 +80,12 @@ struct Builder {
         Box cb; cb.reset();
         for(int i = first; i < first + count; ++i){ bb.grow(prims[i].box); cb.grow(prims[i].cen); }
         out_box = bb;
-        if(count <= kMaxLeafTris) return make_leaf(first, count);
+        if(count <= max_leaf) return make_leaf(first, count);
 
         // levels still available below this node; force balanced splits when they run short
         int remaining = kMaxBvhDepth - depth;
         int need = 0;
-        { int leaves = (count + kMaxLeafTris - 1) / kMaxLeafTris; while((1 << need) < leaves) ++need; }
+        { int leaves = (count + max_leaf - 1) / max_leaf; while((1 << need) < leaves) ++need; }
         bool force_median = need >= remaining;
 
         int axis = 0;
@@ -233,6 +235,7 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
 
     auto t0 = std::chrono::steady_clock::now();
     Builder B;
+    if(const char *e = getenv("HPT_MAX_LEAF")){ int v = atoi(e); if(v >= 1 && v <= 8) B.max_leaf = v; }   // tuning experiments
     B.prims.resize(nt);
     Box scene_box; scene_box.reset();
     for(int i = 0; i < nt; ++i){
@@ -257,7 +260,7 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
         set_empty_box(n.lmin, n.lmax); set_empty_box(n.rmin, n.rmax);
         n.left = n.right = kEmptyChild;
         B.nodes.push_back(n);
-    } else if(nt <= kMaxLeafTris){
+    } else if(nt <= B.max_leaf){
         BvhNode n; memset(&n, 0, sizeof n);
         B.nodes.push_back(n);
         Box lb;

@@ -230,7 +230,7 @@ def test_kernel_timing_stats_are_reported(hpt, sio, input_scene):
     with hpt.Scene(L, sp, tr) as scene:
         scene.render_pt(cam, 256, 256, 4, 8, hpt.make_params(seed=1, flags=hpt.FLAG_TIME_KERNELS))
         st = scene.stats()
-    assert st["n_extend"] >= 4 and st["n_extend"] == st["n_shade"] == st["n_connect"]
+    assert st["n_extend"] >= 4 and st["n_extend"] == st["n_shade"] and st["n_connect"] >= 1
     assert st["ms_extend"] > 0 and st["ms_shade"] > 0 and st["ms_total"] >= st["ms_extend"]
 
 
