@@ -69,3 +69,32 @@ def test_host_tiling_mirror_roundtrip():
             x, y, v = tiling.local_to_pixel(W, H, tile, r, world)
             np.add.at(cover, (y[v], x[v]), 1)
         assert (cover == 1).all()
+
+
+REF_SYMBOL = "_Z17pt_render_wrapperPK9CudaLightiPK10CudaSphereiPK12CudaTrianglei6float3S8_10CudaCameraPS8_iiiiii"
+
+
+def test_reference_named_adapter_exports_the_reference_symbol(tmp_path):
+    """libhpt_ref.so must define pt_render_wrapper under the exact mangled name a caller compiled
+    against the reference's declaration (include/pt_cu.cuh:6-13) asks for.  The expected name is
+    derived independently here: a probe translation unit that declares the function from scratch
+    (opaque record types, CUDA-style float3) is compiled and its undefined symbol is read back."""
+    import subprocess
+    so = os.path.join(ROOT, "path_tracing_amd", "csrc", "libhpt_ref.so")
+    assert os.path.exists(so)
+    probe = tmp_path / "probe.cpp"
+    probe.write_text(
+        "struct float3 { float x, y, z; };\n"
+        "struct CudaLight; struct CudaSphere; struct CudaTriangle;\n"
+        "struct CudaCamera { float3 eye, U, V, W, UL, dx, dy; };\n"
+        "void pt_render_wrapper(const CudaLight *, int, const CudaSphere *, int, const CudaTriangle *, int,\n"
+        "                       float3, float3, const CudaCamera, float3 *, int, int, int, int, int, int);\n"
+        "void call(const CudaLight *l, const CudaSphere *s, const CudaTriangle *t, CudaCamera c, float3 *img){\n"
+        "    float3 z = {0, 0, 0}; pt_render_wrapper(l, 1, s, 1, t, 1, z, z, c, img, 8, 8, 4, 8, 4, 1); }\n")
+    obj = tmp_path / "probe.o"
+    subprocess.check_call(["g++", "-c", "-o", str(obj), str(probe)])
+    undefined = subprocess.check_output(["nm", "-u", str(obj)], text=True)
+    wanted = [ln.split()[-1] for ln in undefined.splitlines() if "pt_render_wrapper" in ln]
+    assert wanted == [REF_SYMBOL]
+    defined = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    assert REF_SYMBOL in defined

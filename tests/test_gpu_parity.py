@@ -244,3 +244,31 @@ def test_errors_surface_as_exceptions(hpt, sio, input_scene):
             scene.render_pt(cam, 16, 16, 0, 1)
         with pytest.raises(hpt.HptError):
             scene.render_pt(cam, 16, 16, 4, 1, hpt.make_params(world=2, rank=0))
+
+
+def test_reference_named_cpp_entry_point(hpt, sio, input_scene, oracle_mod, monkeypatch):
+    """pt_render_wrapper with the reference's C++ signature (by-value float3 / CudaCamera),
+    called through its mangled name exactly as the reference's pt_cu_helper.cpp would."""
+    from test_boundary import REF_SYMBOL
+    from conftest import ROOT
+
+    class F3(C.Structure):
+        _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+    class Cam(C.Structure):
+        _fields_ = [(n, F3) for n in ("eye", "U", "V", "W", "UL", "dx", "dy")]
+
+    sc, (L, sp, tr) = input_scene
+    W = H = 40
+    cam = sio.camera_for(sc, W, H)
+    lib = C.CDLL(os.path.join(ROOT, "path_tracing_amd", "csrc", "libhpt_ref.so"))
+    fn = getattr(lib, REF_SYMBOL)
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, F3, F3, Cam, C.c_void_p] + [C.c_int] * 6
+    ccam = Cam.from_buffer_copy(np.ascontiguousarray(cam).tobytes())
+    img = np.zeros((H, W, 3), np.float32)
+    monkeypatch.setenv("HPT_SEED", "41")
+    fn(L.ctypes.data, len(L), sp.ctypes.data, len(sp), tr.ctypes.data, len(tr), F3(0, 0, 0), F3(0, 0, 0), ccam,
+       img.ctypes.data, W, H, 4, 8, 4, 3)
+    ref, _ = oracle_mod.pt_render(L, sp, tr, cam, W, H, 4, 3, seed=41)
+    assert_parity(img, ref)
