@@ -127,3 +127,61 @@ def visibility(spheres, tris, p1, p2, glass_opaque=False):
     vis = np.empty(n, np.int32)
     lib().oracle_visibility(_p(spheres), len(spheres), _p(tris), len(tris), _p(p1), _p(p2), n, int(glass_opaque), _p(vis))
     return vis
+
+
+class BdptOpts(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("rng_mode", C.c_int), ("threads", C.c_int),
+                ("x0", C.c_int), ("y0", C.c_int), ("x1", C.c_int), ("y1", C.c_int), ("max_delta", C.c_int)]
+
+
+class BdptStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "connections", "tri_tests", "sphere_tests")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def object_order(scene_desc=None, spheres=None, tris=None):
+    """(kind, index, group) arrays: the scene file's insertion order per group when a parsed
+    SceneDesc is given, otherwise spheres then triangles in one group."""
+    kind, index, group = [], [], []
+    if scene_desc is not None:
+        ns = nt = 0
+        for gid in sorted(scene_desc.groups):
+            for obj in scene_desc.groups[gid]:
+                if obj[0] == "S":
+                    kind.append(0); index.append(ns); ns += 1
+                else:
+                    kind.append(1); index.append(nt); nt += 1
+                group.append(gid)
+    else:
+        for i in range(len(spheres)):
+            kind.append(0); index.append(i); group.append(0)
+        for i in range(len(tris)):
+            kind.append(1); index.append(i); group.append(0)
+    return (np.asarray(kind, np.int32), np.asarray(index, np.int32), np.asarray(group, np.int32))
+
+
+def bdpt_render(lights, spheres, tris, order, eye, look_at, view_up, fov_deg, W, H, eye_depth=4, light_depth=4,
+                spp=4, spl=8, *, seed=1, rng_mode=0, threads=0, window=None, rows=None, max_delta=0):
+    """The cpu_bdpt estimator (restates src/cpu_bdpt.cpp:173-488).  rng_mode=1 replays the
+    reference's std::mt19937 streams (bit-reproducible with threads=1; `rows` limits the render to
+    the first rows).  Returns (image[H,W,3], stats)."""
+    img = np.zeros((H, W, 3), np.float32)
+    o = BdptOpts()
+    o.seed, o.rng_mode, o.threads, o.max_delta = int(seed), rng_mode, threads, max_delta
+    o.x0, o.y0, o.x1, o.y1 = window if window else (0, 0, W, H)
+    if rows is not None:
+        o.y1 = rows
+    st = BdptStats()
+    cam = np.concatenate([np.asarray(eye, np.float32), np.asarray(look_at, np.float32), np.asarray(view_up, np.float32),
+                          np.asarray([fov_deg], np.float32)]).astype(np.float32)
+    kind, index, group = (np.ascontiguousarray(a, np.int32) for a in order)
+    lights = np.ascontiguousarray(lights); spheres = np.ascontiguousarray(spheres); tris = np.ascontiguousarray(tris)
+    fn = lib().oracle_bdpt_render
+    fn.restype = C.c_int
+    rc = fn(_p(lights), len(lights), _p(spheres), len(spheres), _p(tris), len(tris), _p(kind), _p(index), _p(group), len(kind),
+            _p(cam), _p(img), W, H, eye_depth, light_depth, spp, spl, C.byref(o), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle_bdpt_render failed rc=%d" % rc)
+    return img, st.as_dict()
