@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--tris", type=int, default=100_000)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r01_pmc_extend.json"))
+    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
@@ -127,7 +127,7 @@ def main():
     for _ in range(args.steps):
         step(hpt.FLAG_TIME_KERNELS)        # HIP events around every launch, on the launch stream
         st = scene.stats()                 # waits for this rank's render
-        ext_ms += st["ms_extend"]; ext_n += st["n_extend"]; tot_ms += st["ms_total"]
+        ext_ms += st["ms_extend"] + st["ms_connect"]; ext_n += st["n_extend"] + st["n_connect"]; tot_ms += st["ms_total"]
         shade_ms, connect_ms, other_ms = st["ms_shade"], st["ms_connect"], st["ms_other"]
     fence()
     dt = time.perf_counter() - t0
@@ -144,10 +144,12 @@ def main():
     if rank == 0:
         samples = W * H * args.spp
         value = samples * args.steps / dt / 1e6
-        # dominant kernel: k_extend (closest-hit BVH traversal).  Algorithmic bytes per launch:
-        # 32 B per child box tested + 36 B per triangle tested + 44 B per ray (origin+direction
-        # in, queue index in, hit record out), DESIGN.md "Kernels".
-        ext_bytes = 32.0 * wc["boxes_closest"] + 36.0 * wc["tris_closest"] + 44.0 * wc["closest_rays"]
+        # dominant kernel: k_trace (closest-hit + any-hit BVH traversal, one merged launch per
+        # iteration).  Algorithmic bytes per launch: 32 B per child box slab-tested + 36 B per triangle
+        # tested + 44 B per closest-hit ray (queue index, origin, direction in; hit record out) + 36 B
+        # per shadow ray (queue index, origin|max, direction in) -- DESIGN.md "Kernels".
+        ext_bytes = (32.0 * (wc["boxes_closest"] + wc["boxes_shadow"]) + 36.0 * (wc["tris_closest"] + wc["tris_shadow"])
+                     + 44.0 * wc["closest_rays"] + 36.0 * wc["shadow_rays"])
         avg_launch_ms = ext_ms / max(ext_n, 1)
         launches_per_render = ext_n / max(args.steps, 1)
         bytes_per_launch = ext_bytes / max(launches_per_render, 1)
@@ -171,19 +173,19 @@ def main():
                                    % (len(tris), W, H, args.spp, args.depth),
                        "parallelism": "image tiles 32x32 round-robin over %d rank(s), RCCL gather to rank 0" % world,
                        "seed": 1},
-            "roofline": {"bound": "hbm", "kernel": "k_extend (closest-hit BVH traversal)",
+            "roofline": {"bound": "hbm", "kernel": "k_trace (closest-hit + any-hit BVH traversal)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy_peak": achieved / HBM_ACHIEVABLE_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_render,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "rank 0's kernels; bytes = 32*boxes + 36*tris + 44*rays of this rank"},
+                         "note": "rank 0's kernels; bytes = 32*boxes + 36*tris + 44*closest rays + 36*shadow rays of this rank"},
             "work": {"rays_per_sample": all_rays / max(wc["samples"], 1),
                      "boxes_per_ray": (wc["boxes_closest"] + wc["boxes_shadow"]) / max(all_rays, 1),
                      "tris_per_ray": (wc["tris_closest"] + wc["tris_shadow"]) / max(all_rays, 1),
                      "algorithmic_bytes_per_sample": per_sample,
                      "Mrays_per_s": all_rays * world / (dt / args.steps) / 1e6 if world == 1 else None,
                      "device_ms_per_step_rank0": tot_ms / args.steps,
-                     "kernel_ms_last_step_rank0": {"extend": st["ms_extend"], "shade": shade_ms, "connect": connect_ms, "other": other_ms},
+                     "kernel_ms_last_step_rank0": {"trace": st["ms_extend"] + st["ms_connect"], "shade": shade_ms, "other": other_ms},
                      "bvh_nodes": wc["bvh_nodes"], "bvh_depth": wc["bvh_depth"], "ms_bvh_build": wc["ms_bvh_build"]},
         }
         if world == 1 and not args.no_cpu_baseline:

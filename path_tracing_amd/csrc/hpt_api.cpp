@@ -206,8 +206,9 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         const bool legacy = brute || (P.reserved & 1);      // separate extend/connect kernels (the scan variants)
         int pending_shadow = -1;                            // iteration whose shadow queue is not traced yet
         for(int it = 0; it < max_iters; ++it){
-            if(it >= eye_depth){
-                // only free delta bounces can keep a path alive this long: look before launching
+            if(it >= eye_depth && ((it - eye_depth) & 1) == 0){
+                // only free delta bounces can keep a path alive this long: look before launching,
+                // every other iteration (an empty launch costs less than a read-back)
                 HIP_TRY(hipMemcpyAsync(s->h_count, &qcnt[it], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 if(*s->h_count == 0u) break;

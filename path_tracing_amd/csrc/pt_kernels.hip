@@ -609,6 +609,7 @@ void k_untile(Tiling tl, const float *gathered, float *image){
 // a launch to a few workgroups); refill threshold 8 -> 51.0, 16 -> 49.6, 32 -> 48.6, 48 -> 48.0.
 constexpr int kTraceChunk = 512;      // rays per workgroup
 constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
+constexpr uint32_t kTraceShortQueue = 1u << 20;   // below this many rays a workgroup takes 256 instead of kTraceChunk
 
 template <bool ANY, bool COUNT>
 HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *queue,
@@ -789,14 +790,18 @@ void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, cons
     extern __shared__ uint32_t s_dyn_stack[];        // [stack level][lane], sized by the BVH depth
     __shared__ uint32_t s_next;
     uint32_t ecount = ecount_ptr ? *ecount_ptr : 0u, scount = scount_ptr ? *scount_ptr : 0u;
-    uint32_t ne = (ecount + chunk_rays - 1) / chunk_rays, ns = (scount + chunk_rays - 1) / chunk_rays;
+    // short queues (the delta-bounce tail) get one ray per lane so they spread over every CU
+    uint32_t ce = ecount >= kTraceShortQueue ? chunk_rays : (uint32_t) kBlock;
+    uint32_t cs = scount >= kTraceShortQueue ? chunk_rays : (uint32_t) kBlock;
+    uint32_t ne = (ecount + ce - 1) / ce, ns = (scount + cs - 1) / cs;
     uint32_t bid = blockIdx.x;
     if(bid >= ne + ns) return;
     bool shadow = bid >= ne;
     uint32_t chunk = shadow ? bid - ne : bid;
-    uint32_t begin = chunk * chunk_rays;
+    uint32_t csize = shadow ? cs : ce;
+    uint32_t begin = chunk * csize;
     uint32_t total = shadow ? scount : ecount;
-    uint32_t end = begin + chunk_rays < total ? begin + chunk_rays : total;
+    uint32_t end = begin + csize < total ? begin + csize : total;
     if(threadIdx.x == 0) s_next = begin;
     __syncthreads();
     if(shadow) trace_chunk<true, COUNT>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, wc);
@@ -890,7 +895,15 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
                   uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc){
     uint32_t chunk = ((tuning >> 16) & 0xFF) ? (uint32_t) ((tuning >> 16) & 0xFF) * 256u : (uint32_t) kTraceChunk;
     int refill_min = ((tuning >> 8) & 0xFF) ? ((tuning >> 8) & 0xFF) : kRefillMin;
-    uint32_t g = (ecount ? (max_extend + chunk - 1) / chunk : 0u) + (scount ? (max_shadow + chunk - 1) / chunk : 0u);
+    // worst-case grid for either chunking regime of k_trace (long queues: `chunk` rays per workgroup,
+    // queues shorter than kTraceShortQueue: kBlock rays per workgroup)
+    auto groups = [&](uint32_t items){
+        uint32_t a = (items + chunk - 1) / chunk;
+        uint32_t shortest = items < kTraceShortQueue ? items : kTraceShortQueue;
+        uint32_t b = (shortest + kBlock - 1) / kBlock;
+        return a > b ? a : b;
+    };
+    uint32_t g = (ecount ? groups(max_extend) : 0u) + (scount ? groups(max_shadow) : 0u);
     if(g == 0u) return;
     if(stack_levels < 1) stack_levels = 1;
     if(stack_levels > kStackDepth) stack_levels = kStackDepth;

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round profile: kernel-trace stats of the bench command + FETCH_SIZE / WRITE_SIZE passes (separate runs).
+# Usage on the GPU box:  bash scripts/profile_round.sh <tag>
+set -u
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+TAG="${1:-r01}"
+OUT="$ROOT/gpurun_out/$TAG"
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+echo "trace exit $?"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 32 --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1
+  echo "pmc $C exit $?"
+done
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/pmc_TCC" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 32 --no-cpu-baseline > "$OUT/pmc_TCC.log" 2>&1
+echo "pmc TCC exit $?"

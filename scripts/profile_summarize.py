@@ -1,0 +1,40 @@
+"""Turns gpurun_out/<tag> (scripts/profile_round.sh) into the committed profiles/<tag>_* files."""
+import csv, glob, json, os, sys, collections, shutil
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01b"
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(ks, os.path.join("profiles", "%s_kernel_stats.csv" % tag))
+def kname(n):
+    for k in ("k_trace", "k_shade", "k_generate", "k_resolve", "k_finalize", "k_untile", "k_extend", "k_connect"):
+        if k in n: return k
+    return None
+out = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC"):
+    fs = glob.glob(os.path.join(src, "pmc_" + c, "*", "*_counter_collection.csv"))
+    if not fs: continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(fs[0])):
+        k = kname(r["Kernel_Name"])
+        if not k: continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+    for k in agg:
+        for cn, v in agg[k].items(): out[k][cn] = v
+        out[k]["dispatches"] = len(disp[k])
+res = {"tag": tag, "workload": "bench.py --steps 1 --warmup 0 --spp 32 (cfg3 scene, 1024x1024), one PMC counter set per run",
+       "note": "FETCH_SIZE/WRITE_SIZE are in KiB, summed over the kernel's dispatches; on gfx950 FETCH_SIZE tallies 128-B "
+               "requests as 64 B (MI355X_MICROARCH.md, HBM section): read bytes = 2 x FETCH_SIZE x 1024; counts fabric-side "
+               "requests including Infinity-Cache hits", "kernels": {}}
+for k, a in out.items():
+    d = {"dispatches": a.get("dispatches")}
+    if "FETCH_SIZE" in a: d["FETCH_SIZE_KiB"] = a["FETCH_SIZE"]; d["read_bytes_corrected"] = 2 * 1024 * a["FETCH_SIZE"]
+    if "WRITE_SIZE" in a: d["WRITE_SIZE_KiB"] = a["WRITE_SIZE"]; d["write_bytes"] = 1024 * a["WRITE_SIZE"]
+    if "TCC_HIT_sum" in a: d["l2_hit_rate"] = a["TCC_HIT_sum"] / max(a["TCC_HIT_sum"] + a["TCC_MISS_sum"], 1); d["TCC_REQ_sum"] = a["TCC_REQ_sum"]
+    if "read_bytes_corrected" in d and "write_bytes" in d and d["dispatches"]:
+        d["hbm_bytes_per_launch"] = (d["read_bytes_corrected"] + d["write_bytes"]) / d["dispatches"]
+    res["kernels"][k] = d
+if "k_trace" in res["kernels"]:
+    res["hbm_bytes_per_launch"] = res["kernels"]["k_trace"].get("hbm_bytes_per_launch")
+json.dump(res, open(os.path.join("profiles", "%s_pmc_traffic.json" % tag), "w"), indent=1)
+print(json.dumps(res, indent=1))
+print(open(os.path.join("profiles", "%s_kernel_stats.csv" % tag)).read()[:1500])
