@@ -161,12 +161,23 @@ HPT_DEV f3 sample_visible_normal(f3 wo, float alpha, float u1, float u2){
     return normalize3(mk3(alpha * Nh.x, alpha * Nh.y, fmaxf(0.0f, Nh.z)));
 }
 
-// BSDF value and pdf in one pass over the shared local-frame terms (the two reference
-// functions, geometric.cuh:419-456 and 458-484, build the same frame and half vector).
-HPT_DEV void bsdf_eval_pdf(const Mat &m, f3 wo_w, f3 wi_w, f3 N, f3 &f_out, float &pdf_out){
-    f3 T, B; build_local_frame(N, T, B);
-    f3 wo = to_local(wo_w, T, B, N);
-    f3 wi = to_local(wi_w, T, B, N);
+// Shading context shared by every BSDF query at one hit point: the reference's evaluate / pdf /
+// sample each rebuild the same local frame from N and re-project the same wo
+// (geometric.cuh:421-424, 460-462, 495-497); building them once gives identical values.
+struct ShadeCtx { f3 T, B, N; f3 wo; };
+
+HPT_DEV ShadeCtx make_shade_ctx(f3 N, f3 wo_w){
+    ShadeCtx c; c.N = N;
+    build_local_frame(N, c.T, c.B);
+    c.wo = to_local(wo_w, c.T, c.B, N);
+    return c;
+}
+
+// BSDF value and pdf in one pass over the shared terms (the two reference functions,
+// geometric.cuh:419-456 and 458-484, build the same half vector, D and Lambda(wo)).
+HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, float &pdf_out){
+    f3 wo = c.wo;
+    f3 wi = to_local(wi_w, c.T, c.B, c.N);
     f_out = mk3(0, 0, 0); pdf_out = 0.0f;
     bool eval_zero = (wo.z == 0.0f || wi.z == 0.0f);
     bool pdf_zero = (wo.z * wi.z <= 0.0f);
@@ -202,13 +213,12 @@ HPT_DEV void bsdf_eval_pdf(const Mat &m, f3 wo_w, f3 wi_w, f3 N, f3 &f_out, floa
 
 // BSDF sampling (geometric.cuh:486-562).  pdf <= 0 means "terminate the path" for both the
 // non-delta rejection and the reference's uninitialised total-internal-reflection return.
-HPT_DEV void bsdf_sample(const Mat &m, f3 wo_w, f3 N, float u_rr, float u1, float u2, float cur_eta,
+HPT_DEV void bsdf_sample(const Mat &m, const ShadeCtx &c, float u_rr, float u1, float u2, float cur_eta,
                          f3 &wi_w, f3 &f, float &pdf, bool &is_delta, float &new_eta){
     is_delta = false;
     new_eta = cur_eta;
     wi_w = mk3(0, 0, 0); f = mk3(0, 0, 0); pdf = 0.0f;
-    f3 T, B; build_local_frame(N, T, B);
-    f3 wo = to_local(wo_w, T, B, N);
+    f3 wo = c.wo;
     f3 wi;
     if(m.eta > 0.0f && m.roughness < 0.001f && m.metallic < 0.01f){
         is_delta = true;
@@ -229,7 +239,7 @@ HPT_DEV void bsdf_sample(const Mat &m, f3 wo_w, f3 N, float u_rr, float u1, floa
             pdf = 1.0f - F;
             f = m.base * (1.0f - F) / fabsf(wi.z);
         }
-        wi_w = to_world(wi, T, B, N);
+        wi_w = to_world(wi, c.T, c.B, c.N);
         return;
     }
     if(m.metallic > 0.99f && m.roughness < 0.001f){
@@ -237,7 +247,7 @@ HPT_DEV void bsdf_sample(const Mat &m, f3 wo_w, f3 N, float u_rr, float u1, floa
         wi = mk3(-wo.x, -wo.y, wo.z);
         pdf = 1.0f;
         f = fr_schlick(fabsf(wo.z), m.base) / fabsf(wi.z);
-        wi_w = to_world(wi, T, B, N);
+        wi_w = to_world(wi, c.T, c.B, c.N);
         return;
     }
     float alpha = roughness_to_alpha(m.roughness);
@@ -253,8 +263,8 @@ HPT_DEV void bsdf_sample(const Mat &m, f3 wo_w, f3 N, float u_rr, float u1, floa
         wi = mk3(r * cs, r * sn, sqrtf(fmaxf(0.0f, 1.0f - u1)));
         if(wo.z < 0.0f) wi.z *= -1.0f;
     }
-    wi_w = to_world(wi, T, B, N);
-    bsdf_eval_pdf(m, wo_w, wi_w, N, f, pdf);
+    wi_w = to_world(wi, c.T, c.B, c.N);
+    bsdf_eval_pdf(m, c, wi_w, f, pdf);
 }
 
 // ---- primitive tests --------------------------------------------------------------------

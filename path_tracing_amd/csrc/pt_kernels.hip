@@ -420,6 +420,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     m.roughness = dm.roughness; m.metallic = dm.metallic; m.eta = dm.eta;
                     uint2 r2 = pb.rng[path];
                     uint64_t rs = ((uint64_t) r2.y << 32) | (uint64_t) r2.x;
+                    const ShadeCtx ctx = make_shade_ctx(normal, wo);
 
                     // next-event estimation, pt_cu.cu:125-202
                     if(m.eta <= 0.0f && (m.metallic < 0.99f || m.roughness > 0.01f) && sc.num_lights > 0){
@@ -431,7 +432,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                             float cos_surface = fmaxf(0.0f, dot3(normal, light_dir));
                             if(cos_surface > 0.0f){
                                 f3 brdf; float pdf_unused;
-                                bsdf_eval_pdf(m, wo, light_dir, normal, brdf, pdf_unused);
+                                bsdf_eval_pdf(m, ctx, light_dir, brdf, pdf_unused);
                                 f3 contrib = throughput * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface * (float) sc.num_lights;
                                 if(is_valid_color(contrib)){
                                     want_shadow = true;
@@ -464,7 +465,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                                     float pdf_light_area = 1.0f / (sc.num_lights * L.area);
                                     float pdf_light_dir = pdf_light_area * dist2 / fmaxf(cos_light, 1e-6f);
                                     f3 brdf; float pdf_bsdf;
-                                    bsdf_eval_pdf(m, wo, wi_light, normal, brdf, pdf_bsdf);
+                                    bsdf_eval_pdf(m, ctx, wi_light, brdf, pdf_bsdf);
                                     float p_l = pdf_light_dir * pdf_light_dir;
                                     float p_b = pdf_bsdf * pdf_bsdf;
                                     float mis_w = p_l / fmaxf(p_l + p_b, 1e-8f);
@@ -483,7 +484,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     // BSDF sampling and path continuation, pt_cu.cu:204-241
                     float u_rr = rng_next(rs), u1 = rng_next(rs), u2 = rng_next(rs);
                     f3 wi, bsdf_val; float pdf_omega, new_eta; bool is_delta;
-                    bsdf_sample(m, wo, normal, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
+                    bsdf_sample(m, ctx, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
                     if(!(pdf_omega <= 0.0f)){          // pt_cu.cu:214 (and the TIR return, defined: terminate)
                         f3 new_o;
                         if(is_delta){
