@@ -1,0 +1,117 @@
+"""The C++ host mirror (path_tracing_amd/csrc/host/: scene grammar, flattening, camera, output
+stage, CLI clone) against the Python mirror and, on the GPU, end to end through pt_cli."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+CSRC = os.path.join(ROOT, "path_tracing_amd", "csrc")
+
+
+def _host():
+    lib = C.CDLL(os.path.join(CSRC, "libhpt_host.so"))
+    lib.hpt_host_flatten_scene_file.restype = C.c_int
+    return lib
+
+
+def _flatten_cpp(path, W, H):
+    from path_tracing_amd.layouts import CAMERA, LIGHT, SPHERE, TRIANGLE
+    lib = _host()
+    nl, ns, nt = C.c_int(), C.c_int(), C.c_int()
+    pl, ps, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    cam = np.zeros((), CAMERA)
+    res = (C.c_int * 2)()
+    rc = lib.hpt_host_flatten_scene_file(path.encode(), C.byref(nl), C.byref(ns), C.byref(nt), C.byref(pl), C.byref(ps), C.byref(pt),
+                                         cam.ctypes.data_as(C.c_void_p), W, H, res)
+    assert rc == 0
+    get = lambda p, n, dt: np.frombuffer(C.string_at(p, n * dt.itemsize), dt).copy() if n else np.zeros(0, dt)
+    return get(pl, nl.value, LIGHT), get(ps, ns.value, SPHERE), get(pt, nt.value, TRIANGLE), cam, (res[0], res[1])
+
+
+@pytest.mark.parametrize("name", ["input", "mis_test"])
+def test_cpp_parser_flattening_and_camera_match_python_mirror(sio, name):
+    path = os.path.join(GOLDEN, "scenes", name + ".txt")
+    L, sp, tr, cam, res = _flatten_cpp(path, 200, 120)
+    sc = sio.load_scene(path)
+    L2, sp2, tr2 = sio.flatten_for_pt(sc)
+    assert res == tuple(sc.resolution)
+    assert L.tobytes() == L2.tobytes() and sp.tobytes() == sp2.tobytes() and tr.tobytes() == tr2.tobytes()
+    cam2 = sio.camera_for(sc, 200, 120, 50.0)
+    assert cam.tobytes() == cam2.tobytes()
+
+
+def test_png_and_pfm_output_stage(tmp_path):
+    lib = _host()
+    rng = np.random.default_rng(0)
+    img = (rng.random((7, 5, 3)) * 1.5 - 0.1).astype(np.float32)
+    png = str(tmp_path / "o.png")
+    assert lib.hpt_host_write_image(png.encode(), img.ctypes.data_as(C.c_void_p), 5, 7) == 0
+    data = open(png, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    # decode: IHDR, IDAT
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(tag + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if tag == b"IHDR": ihdr = struct.unpack(">IIBBBBB", body)
+        if tag == b"IDAT": idat += body
+        pos += 12 + n
+    assert ihdr == (5, 7, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(7, 1 + 15)
+    assert not raw[:, 0].any()
+    got = raw[:, 1:].reshape(7, 5, 3)
+    want = (np.power(np.clip(img, 0, 1), np.float32(1 / 2.2)) * np.float32(255)).astype(np.uint8)   # src/main_cli.cpp:233-242
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    pfm = str(tmp_path / "o.pfm")
+    assert lib.hpt_host_write_image(pfm.encode(), img.ctypes.data_as(C.c_void_p), 5, 7) == 0
+    blob = open(pfm, "rb").read()
+    head = b"PF\n5 7\n-1.0\n"
+    assert blob.startswith(head)
+    back = np.frombuffer(blob[len(head):], np.float32).reshape(7, 5, 3)[::-1]
+    assert np.array_equal(back, img)
+
+
+def test_cli_help_and_missing_scene():
+    cli = os.path.join(CSRC, "pt_cli")
+    out = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--spp <int>" in out.stdout and "--seed" in out.stdout
+    out = subprocess.run([cli, "--input", "/nonexistent/scene.txt"], capture_output=True, text=True)
+    assert out.returncode != 0 and "[Error] Cannot open input file" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cli_renders_the_same_image_as_the_oracle(tmp_path, sio, oracle_mod):
+    cli = os.path.join(CSRC, "pt_cli")
+    scene = os.path.join(GOLDEN, "scenes", "input.txt")
+    out = str(tmp_path / "img.pfm")
+    run = subprocess.run([cli, "--input", scene, "--output", out, "--spp", "3", "--seed", "17", "--width", "48", "--height", "40"],
+                         capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    for needle in ("Mode   : pt", "Triangle:\n36", "Ball:\n5", "Light:\n4", "moved", "[Render] Finished in", "[Success] Image saved!"):
+        assert needle in run.stdout
+    blob = open(out, "rb").read()
+    head = b"PF\n48 40\n-1.0\n"
+    img = np.frombuffer(blob[len(head):], np.float32).reshape(40, 48, 3)[::-1]
+    sc = sio.load_scene(scene)
+    L, sp, tr = sio.flatten_for_pt(sc)
+    ref, _ = oracle_mod.pt_render(L, sp, tr, sio.camera_for(sc, 48, 40), 48, 40, 4, 3, seed=17)
+    assert float(np.sqrt(((img - ref) ** 2).mean())) < 1e-3 and float(np.abs(img - ref).max()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_cli_obj_ingestion(tmp_path):
+    cli = os.path.join(CSRC, "pt_cli")
+    obj = tmp_path / "quad.obj"
+    obj.write_text("v -0.2 -0.2 0.5\nv 0.2 -0.2 0.5\nv 0.2 0.2 0.5\nv -0.2 0.2 0.5\nf 1 2 3 4\nf -4//1 -3//1 -2//1\n")
+    out = str(tmp_path / "q.png")
+    run = subprocess.run([cli, "--input", os.path.join(GOLDEN, "scenes", "input.txt"), "--obj", str(obj), "--output", out,
+                          "--spp", "2", "--seed", "1", "--width", "32", "--height", "32"], capture_output=True, text=True)
+    assert run.returncode == 0 and "OBJ triangles: 3" in run.stdout and "Triangle:\n39" in run.stdout
+    assert os.path.getsize(out) > 100
