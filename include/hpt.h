@@ -134,6 +134,30 @@ int hpt_pt_render_wrapper(const void *lights, int num_lights,
                           int light_depth, int light_sample, int eye_depth, int spp,
                           int64_t seed);
 
+/* ---- bidirectional estimator of the reference's CPU renderer ------------------------------------
+ * Replaces bdpt_render_wrapper (reference include/bdpt_cu.cuh:30-37, src/bdpt_cu.cu:538-674) and
+ * run_cuda_bdpt (include/bdpt_cu_helper.h:6).  What is computed follows run_cpu_bdpt (reference
+ * src/cpu_bdpt.cpp:173-488) wherever it and the CUDA BDPT kernel disagree: the CPU scene
+ * model with its one-level group boxes, nl*spl light subpaths carrying illum/spl, every eye vertex
+ * connected to every light vertex with the ratio-sum MIS weight.
+ *
+ * hpt_scene_set_groups hands over the scene file's grouping (kind 0 sphere / 1 triangle, index into
+ * the arrays given to hpt_scene_create, group id; insertion order), which decides tie-breaks and the
+ * per-group box culls of the CPU model.  Without it: one group, spheres then triangles. */
+int hpt_scene_set_groups(hpt_scene *scene, const int32_t *obj_kind, const int32_t *obj_index,
+                         const int32_t *obj_group, int num_objects);
+int hpt_render_bdpt(hpt_scene *scene, const void *camera, int W, int H, int eye_depth, int light_depth,
+                    int spp, int spl, const hpt_params *params, float *host_image);
+int hpt_render_bdpt_device(hpt_scene *scene, const void *camera, int W, int H, int eye_depth, int light_depth,
+                           int spp, int spl, const hpt_params *params, void *d_local, void *hip_stream);
+/* One-shot, argument list of the reference's bdpt_render_wrapper; the lights arrive with illum already
+ * divided by light_sample (reference src/bdpt_cu_helper.cpp:60-62), which is undone here. */
+int hpt_bdpt_render_wrapper(const void *lights, int num_lights, const void *spheres, int num_spheres,
+                            const void *triangles, int num_triangles,
+                            const float scene_min[3], const float scene_max[3],
+                            const void *camera, float *host_image, int W, int H,
+                            int light_depth, int light_sample, int eye_depth, int spp, int spl, int64_t seed);
+
 int hpt_get_stats(const hpt_scene *scene, hpt_stats *out);
 
 /* Ray-level probes of the intersection kernels (tests): n rays, origins/directions as

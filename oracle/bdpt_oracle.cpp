@@ -249,7 +249,8 @@ int oracle_bdpt_render(const void *lights_v, int nl, const void *spheres_v, int 
     if(!camera10 || !image || !opts || W <= 0 || H <= 0 || spp <= 0 || spl <= 0 || eye_depth <= 0 || light_depth <= 0) return 1;
     if(nl == 0) return 0;                                             // src/cpu_bdpt.cpp:178
     OracleBdptOpts o = *opts;
-    if(o.max_delta <= 0) o.max_delta = 10000;
+    if(o.max_delta <= 0) o.max_delta = o.rng_mode == 0 ? 64 : 10000;      // counter mode shares the GPU path's cap
+    const int trig = o.rng_mode == 0 ? 0 : 1;                              // polynomial sincos with the counter streams
     BScene sc;
     sc.lights = (const RLight *) lights_v; sc.nl = nl;
     sc.spheres = (const RSphere *) spheres_v; sc.tris = (const RTriangle *) tris_v;
@@ -276,6 +277,9 @@ int oracle_bdpt_render(const void *lights_v, int nl, const void *spheres_v, int 
             g.objs.push_back(ob);
         }
         for(auto &kv : gm) sc.groups.push_back(kv.second);
+        // intersectAABB widens a degenerate axis every time it runs (src/object.cpp:108-111); start from the box it settles on
+        for(Group &g : sc.groups){ float *mn = &g.mn.x, *mx = &g.mx.x;
+            for(int a = 0; a < 3; ++a) for(int guard = 0; guard < 64 && mx[a] - mn[a] < 1e-6f; ++guard){ mn[a] -= 0.5f * 1e-6f; mx[a] += 0.5f * 1e-6f; } }
     }
     // scene bounds (parallel-light emission), src/cpu_bdpt.cpp:181-187
     V3 c_min = v3(1e9f, 1e9f, 1e9f), c_max = v3(-1e9f, -1e9f, -1e9f);
@@ -340,9 +344,19 @@ int oracle_bdpt_render(const void *lights_v, int nl, const void *spheres_v, int 
                 V3 v_vec = normalize(cross(w, u_vec));
                 u_vec = normalize(cross(v_vec, w));
                 float u1 = rng.next(), u2 = rng.next();
-                float th = acosf(1.0f - u1 * (1.0f - cosf(light.cutoff)));
-                float phi = 2.0f * kPi * u2;
-                V3 local_dir = v3(sinf(th) * cosf(phi), sinf(th) * sinf(phi), cosf(th));
+                V3 local_dir;
+                if(trig == 1){
+                    float th = acosf(1.0f - u1 * (1.0f - cosf(light.cutoff)));
+                    float phi = 2.0f * kPi * u2;
+                    local_dir = v3(sinf(th) * cosf(phi), sinf(th) * sinf(phi), cosf(th));
+                } else {
+                    // counter mode (shared with the HIP kernels): cos(theta) directly, sin from cos,
+                    // phi through the polynomial sincos -- no acosf/sinf/cosf
+                    float cos_t = 1.0f - u1 * (1.0f - cosf(light.cutoff));
+                    float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+                    float sp, cp; sincos_2pi_poly(u2, sp, cp);
+                    local_dir = v3(sin_t * cp, sin_t * sp, cos_t);
+                }
                 ray_d = normalize(u_vec * local_dir.x + v_vec * local_dir.y + w * local_dir.z);
                 ray_o = ray_o + ray_d * light.light_ball.r;
             }
@@ -372,7 +386,7 @@ int oracle_bdpt_render(const void *lights_v, int nl, const void *spheres_v, int 
                 V3 wo = ray_d * -1.0f;
                 V3 wi, bsdf_val; float pdf_omega, new_eta; bool is_delta;
                 float u_rr = rng.next(), u1 = rng.next(), u2 = rng.next();
-                bsdf_sample(1, hit.mtl, wo, hit.normal, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
+                bsdf_sample(trig, hit.mtl, wo, hit.normal, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
                 if(pdf_omega <= 0.0f) break;            // non-delta: :299; delta: the TIR return (defined: terminate)
                 if(is_delta){
                     throughput = throughput * bsdf_val;
@@ -480,7 +494,7 @@ int oracle_bdpt_render(const void *lights_v, int nl, const void *spheres_v, int 
                     V3 wo = ray_d * -1.0f;
                     V3 wi, bsdf_val; float pdf_omega, new_eta; bool is_delta;
                     float u_rr = rng.next(), u1 = rng.next(), u2 = rng.next();
-                    bsdf_sample(1, hit.mtl, wo, hit.normal, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
+                    bsdf_sample(trig, hit.mtl, wo, hit.normal, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
                     if(pdf_omega <= 0.0f) break;
                     if(is_delta){
                         throughput = throughput * bsdf_val;

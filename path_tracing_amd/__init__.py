@@ -70,7 +70,8 @@ def load_library() -> C.CDLL:
         lib.hpt_last_error.restype = C.c_char_p
         lib.hpt_local_pixels.restype = C.c_int64
         lib.hpt_local_pixels.argtypes = [C.c_int, C.c_int, C.POINTER(Params)]
-        for name in ("hpt_scene_create", "hpt_render_pt", "hpt_render_pt_device", "hpt_untile",
+        for name in ("hpt_scene_create", "hpt_render_pt", "hpt_render_pt_device", "hpt_untile", "hpt_scene_set_groups",
+                     "hpt_render_bdpt", "hpt_render_bdpt_device", "hpt_bdpt_render_wrapper",
                      "hpt_pt_render_wrapper", "hpt_get_stats", "hpt_trace_closest", "hpt_trace_visibility",
                      "hpt_device_count"):
             getattr(lib, name).restype = C.c_int
@@ -154,6 +155,24 @@ class Scene:
         cam = np.ascontiguousarray(camera, CAMERA)
         _check(self._lib.hpt_render_pt_device(self._h, _vp(cam.reshape(1)), W, H, eye_depth, spp, C.byref(params),
                                               C.c_void_p(d_local_ptr), C.c_void_p(stream)))
+
+    # -- bidirectional estimator (run_cuda_bdpt, reference include/bdpt_cu_helper.h:6; semantics of run_cpu_bdpt) ---
+    def set_groups(self, kind, index, group):
+        """Scene-file grouping of the objects (kind 0 sphere / 1 triangle, index, group id; insertion order)."""
+        k = np.ascontiguousarray(kind, np.int32); i = np.ascontiguousarray(index, np.int32); g = np.ascontiguousarray(group, np.int32)
+        _check(self._lib.hpt_scene_set_groups(self._h, _vp(k), _vp(i), _vp(g), len(k)))
+
+    def render_bdpt(self, camera, W, H, eye_depth=4, light_depth=4, spp=8, spl=8, params: Params | None = None) -> np.ndarray:
+        params = params or make_params()
+        cam = np.ascontiguousarray(camera, CAMERA)
+        img = np.empty((H, W, 3), np.float32)
+        _check(self._lib.hpt_render_bdpt(self._h, _vp(cam.reshape(1)), W, H, eye_depth, light_depth, spp, spl, C.byref(params), _vp(img)))
+        return img
+
+    def render_bdpt_device(self, camera, W, H, eye_depth, light_depth, spp, spl, params: Params, d_local_ptr: int, stream: int = 0):
+        cam = np.ascontiguousarray(camera, CAMERA)
+        _check(self._lib.hpt_render_bdpt_device(self._h, _vp(cam.reshape(1)), W, H, eye_depth, light_depth, spp, spl, C.byref(params),
+                                                C.c_void_p(d_local_ptr), C.c_void_p(stream)))
 
     def stats(self) -> dict:
         st = Stats()

@@ -10,6 +10,7 @@
 #include "../../include/hpt.h"
 #include "hpt_scene.h"
 #include "pt_kernels.h"
+#include "bdpt_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -63,6 +64,18 @@ struct hpt_scene {
     uint32_t *h_count = nullptr;          // pinned read-back word
     float *d_local_own = nullptr; size_t cap_local_own = 0;
     float *d_image_own = nullptr; size_t cap_image_own = 0;
+
+    // bidirectional (cpu_bdpt-estimator) path: host copy of the records + grouping, device scene built on first use
+    std::vector<unsigned char> h_lights, h_spheres, h_tris;
+    int nl = 0, ns = 0, nt = 0;
+    std::vector<int32_t> g_kind, g_index, g_group;
+    bool bd_ready = false;
+    BdptSceneDev bd{};
+    BvhNode *bd_nodes = nullptr; DevTriangle *bd_tris = nullptr; DevRound *bd_spheres = nullptr; DevGroup *bd_groups = nullptr;
+    DevMaterial *bd_mats = nullptr; DevLight *bd_lights = nullptr;
+    BdptPathBuf bp{}; size_t bd_cap_slots = 0, bd_cap_hist = 0, bd_cap_contrib = 0;
+    LightVertexDev *d_lv = nullptr; size_t bd_cap_lv = 0;
+    uint32_t *cqueue = nullptr; size_t bd_cap_cqueue = 0;
 
     hipEvent_t ev_start = nullptr, ev_stop = nullptr; bool ev_valid = false;
     std::vector<TimedLaunch> timed; std::vector<hipEvent_t> event_pool; size_t event_next = 0;
@@ -277,6 +290,165 @@ int collect_stats(hpt_scene *s){
     return HPT_OK;
 }
 
+
+void free_bdpt_scene(hpt_scene *s){
+    hipFree(s->bd_nodes); hipFree(s->bd_tris); hipFree(s->bd_spheres); hipFree(s->bd_groups); hipFree(s->bd_mats); hipFree(s->bd_lights);
+    s->bd_nodes = nullptr; s->bd_tris = nullptr; s->bd_spheres = nullptr; s->bd_groups = nullptr; s->bd_mats = nullptr; s->bd_lights = nullptr;
+    s->bd_ready = false;
+}
+
+void free_bdpt(hpt_scene *s){
+    free_bdpt_scene(s);
+    hipFree(s->bp.last_pos_pdf); hipFree(s->bp.last_normal); hipFree(s->bp.vtx_pos); hipFree(s->bp.vtx_nrm); hipFree(s->bp.vtx_thr);
+    hipFree(s->bp.vtx_wo); hipFree(s->bp.vtx_base); hipFree(s->bp.hist_pos_eta); hipFree(s->bp.hist_pdf); hipFree(s->bp.contrib);
+    hipFree(s->d_lv); hipFree(s->cqueue);
+    s->bp = BdptPathBuf{}; s->d_lv = nullptr; s->cqueue = nullptr;
+    s->bd_cap_slots = s->bd_cap_hist = s->bd_cap_contrib = s->bd_cap_lv = s->bd_cap_cqueue = 0;
+}
+
+int ensure_bdpt_scene(hpt_scene *s){
+    if(s->bd_ready) return HPT_OK;
+    HostBdptScene hb;
+    bool grouped = !s->g_kind.empty();
+    const char *err = build_bdpt_host_scene(s->h_lights.data(), s->nl, s->h_spheres.data(), s->ns, s->h_tris.data(), s->nt,
+                                            grouped ? s->g_kind.data() : nullptr, grouped ? s->g_index.data() : nullptr,
+                                            grouped ? s->g_group.data() : nullptr, (int) s->g_kind.size(), hb);
+    if(err && *err) return fail(HPT_ERR_INVALID, err);
+    free_bdpt_scene(s);
+    hipError_t e = upload(hb.nodes, &s->bd_nodes);
+    if(e == hipSuccess) e = upload(hb.tris, &s->bd_tris);
+    if(e == hipSuccess) e = upload(hb.spheres, &s->bd_spheres);
+    if(e == hipSuccess) e = upload(hb.groups, &s->bd_groups);
+    if(e == hipSuccess) e = upload(hb.materials, &s->bd_mats);
+    if(e == hipSuccess) e = upload(hb.lights, &s->bd_lights);
+    if(e != hipSuccess) return fail(HPT_ERR_DEVICE, std::string("bdpt scene upload: ") + hipGetErrorString(e));
+    s->bd.nodes = (const float4 *) s->bd_nodes; s->bd.tris = (const float4 *) s->bd_tris; s->bd.spheres = s->bd_spheres;
+    s->bd.groups = s->bd_groups; s->bd.mats = s->bd_mats; s->bd.lights = s->bd_lights;
+    s->bd.num_groups = (int) hb.groups.size(); s->bd.num_lights = s->nl; s->bd.num_mats = (int) hb.materials.size(); s->bd.pad = 0;
+    for(int a = 0; a < 3; ++a){ s->bd.scene_min[a] = hb.scene_min[a]; s->bd.scene_max[a] = hb.scene_max[a]; }
+    s->bd_ready = true;
+    return HPT_OK;
+}
+
+template <typename T>
+int grow(T **p, size_t &cap, size_t need){
+    if(need <= cap) return HPT_OK;
+    hipFree(*p); *p = nullptr; cap = 0;
+    HIP_TRY(hipMalloc((void **) p, need * sizeof(T)));
+    cap = need;
+    return HPT_OK;
+}
+
+// the bidirectional render loop (reference src/cpu_bdpt.cpp:173-488), enqueued on `stream`
+int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, int light_depth, int spp, int spl,
+                      const hpt_params *params, float *d_local, hipStream_t stream){
+    if(!s) return fail(HPT_ERR_INVALID, "null scene");
+    if(!camera || !d_local) return fail(HPT_ERR_INVALID, "null camera or output");
+    if(spp <= 0 || spl <= 0 || eye_depth <= 0 || eye_depth > 255 || light_depth <= 0 || light_depth > 255)
+        return fail(HPT_ERR_INVALID, "spp, spl must be > 0 and depths in [1, 255]");
+    hpt_params P; memset(&P, 0, sizeof P);
+    if(params) P = *params;
+    if(P.max_delta <= 0) P.max_delta = 64;            // the CPU renderer has no cap (cpu_bdpt.cpp:458)
+    if(P.max_delta > 250) P.max_delta = 250;
+    Tiling tl;
+    int rc = make_tiling(W, H, &P, tl);
+    if(rc) return rc;
+    rc = ensure_bdpt_scene(s);
+    if(rc) return rc;
+
+    const int total_light_paths = s->nl * spl;
+    const int n_lv = total_light_paths * light_depth;
+    // slots per pass: bound the contribution table (16 B per pair) to about 1 GiB
+    int spass = P.samples_per_pass;
+    if(spass <= 0){
+        long long pairs = 64ll << 20;
+        long long slots = std::max<long long>(tl.n_local, std::min<long long>(4ll << 20, pairs / std::max(n_lv, 1)));
+        spass = (int) std::max<long long>(1, slots / tl.n_local);
+    }
+    spass = std::min(spass, spp);
+    size_t slots = (size_t) tl.n_local * spass;
+    if(slots > 0x7FFFFFF0ull) return fail(HPT_ERR_INVALID, "too many path slots per pass");
+    const int max_iters = eye_depth + P.max_delta + 1;
+    int n_counters = 2 * (max_iters + 2);
+    rc = ensure_workspace(s, slots, tl.n_local, n_counters);
+    if(rc) return rc;
+    if(slots > s->bd_cap_slots){
+        size_t c;
+        c = s->bd_cap_slots; rc = grow(&s->bp.last_pos_pdf, c, slots); if(rc) return rc;
+        c = s->bd_cap_slots; rc = grow(&s->bp.last_normal, c, slots); if(rc) return rc;
+        c = s->bd_cap_slots; rc = grow(&s->bp.vtx_pos, c, slots); if(rc) return rc;
+        c = s->bd_cap_slots; rc = grow(&s->bp.vtx_nrm, c, slots); if(rc) return rc;
+        c = s->bd_cap_slots; rc = grow(&s->bp.vtx_thr, c, slots); if(rc) return rc;
+        c = s->bd_cap_slots; rc = grow(&s->bp.vtx_wo, c, slots); if(rc) return rc;
+        c = s->bd_cap_slots; rc = grow(&s->bp.vtx_base, c, slots); if(rc) return rc;
+        s->bd_cap_slots = slots;
+        s->bd_cap_hist = 0; s->bd_cap_contrib = 0;
+    }
+    rc = grow(&s->cqueue, s->bd_cap_cqueue, slots); if(rc) return rc;
+    { size_t need = slots * (size_t) eye_depth;
+      if(need > s->bd_cap_hist){
+          size_t c1 = s->bd_cap_hist, c2 = s->bd_cap_hist;
+          rc = grow(&s->bp.hist_pos_eta, c1, need); if(rc) return rc;
+          rc = grow(&s->bp.hist_pdf, c2, need); if(rc) return rc;
+          s->bd_cap_hist = need;
+      } }
+    rc = grow(&s->bp.contrib, s->bd_cap_contrib, slots * (size_t) std::max(n_lv, 1)); if(rc) return rc;
+    rc = grow(&s->d_lv, s->bd_cap_lv, (size_t) std::max(n_lv, 1)); if(rc) return rc;
+
+    const float *cf = (const float *) camera;
+    CameraDev cam;
+    memcpy(cam.eye, cf + 0, 12); memcpy(cam.UL, cf + 12, 12); memcpy(cam.dx, cf + 15, 12); memcpy(cam.dy, cf + 18, 12);
+    s->timed.clear(); s->event_next = 0; s->last_flags = P.flags;
+    s->stats.ms_total = s->stats.ms_extend = s->stats.ms_shade = s->stats.ms_connect = s->stats.ms_other = 0.0;
+    s->stats.n_extend = s->stats.n_shade = s->stats.n_connect = s->stats.n_other = 0;
+    const bool timek = (P.flags & HPT_FLAG_TIME_KERNELS) != 0;
+
+    HIP_TRY(hipMemsetAsync(s->d_wc, 0, sizeof(WorkCounters), stream));
+    HIP_TRY(hipMemsetAsync(s->accum, 0, (size_t) tl.n_local * sizeof(float4), stream));
+    HIP_TRY(hipEventRecord(s->ev_start, stream));
+    if(s->nl > 0){                                       // no lights: the CPU renderer returns at once (cpu_bdpt.cpp:178)
+        { LaunchTimer t(s, stream, timek, 3);
+          launch_bdpt_light_trace(stream, s->bd, s->d_lv, total_light_paths, light_depth, spl, P.seed, P.max_delta); }
+        for(int done = 0; done < spp; done += spass){
+            int sthis = std::min(spass, spp - done);
+            uint32_t nslots = (uint32_t) tl.n_local * (uint32_t) sthis;
+            HIP_TRY(hipMemsetAsync(s->counters, 0, (size_t) n_counters * sizeof(uint32_t), stream));
+            uint32_t *qcnt = s->counters, *ccnt = s->counters + (max_iters + 2);
+            { LaunchTimer t(s, stream, timek, 3);
+              launch_bdpt_generate(stream, tl, cam, s->pb, s->bp, &qcnt[0], sthis, (uint32_t) (P.sample_offset + done), P.seed); }
+            int cur = 0;
+            for(int it = 0; it < max_iters; ++it){
+                const int ci = it;                             // counter slot of this iteration
+                if(it >= eye_depth){
+                    HIP_TRY(hipMemcpyAsync(s->h_count, &qcnt[ci], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    if(*s->h_count == 0u) break;
+                }
+                const uint32_t *eq = it == 0 ? nullptr : s->queue[cur];
+                { LaunchTimer t(s, stream, timek, 0);
+                  launch_bdpt_extend(stream, s->bd, s->pb, eq, &qcnt[ci], nslots); }
+                { LaunchTimer t(s, stream, timek, 1);
+                  launch_bdpt_vertex(stream, s->bd, s->pb, s->bp, eq, &qcnt[ci], nslots, s->queue[cur ^ 1], &qcnt[ci + 1],
+                                     s->cqueue, &ccnt[ci], eye_depth, P.max_delta, (uint32_t) slots); }
+                { LaunchTimer t(s, stream, timek, 2);
+                  launch_bdpt_connect(stream, s->bd, s->pb, s->bp, s->d_lv, n_lv, light_depth, s->cqueue, &ccnt[ci], nslots,
+                                      cam.eye, (uint32_t) slots);
+                  launch_bdpt_reduce(stream, s->pb, s->bp, n_lv, s->cqueue, &ccnt[ci], nslots); }
+                cur ^= 1;
+            }
+            { LaunchTimer t(s, stream, timek, 3);
+              launch_resolve(stream, tl, s->pb, s->accum, sthis); }
+        }
+    }
+    float divisor = (P.flags & HPT_FLAG_OUTPUT_SUM) ? 1.0f : (float) spp;
+    { LaunchTimer t(s, stream, timek, 3);
+      launch_finalize(stream, tl, s->accum, d_local, divisor); }
+    HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    HIP_TRY(hipGetLastError());
+    s->ev_valid = true; s->stats_pending = true;
+    return HPT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -315,6 +487,10 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
     s->sd.rounds = s->d_rounds; s->sd.mats = s->d_mats; s->sd.lights = s->d_lights;
     s->sd.num_rounds = ns + nl; s->sd.num_spheres = ns; s->sd.num_lights = nl; s->sd.num_tris = nt;
     s->sd.num_mats = (int) hs.materials.size(); s->sd.pad = 0;
+    s->nl = nl; s->ns = ns; s->nt = nt;
+    if(nl) s->h_lights.assign((const unsigned char *) lights, (const unsigned char *) lights + (size_t) nl * HPT_LIGHT_BYTES);
+    if(ns) s->h_spheres.assign((const unsigned char *) spheres, (const unsigned char *) spheres + (size_t) ns * HPT_SPHERE_BYTES);
+    if(nt) s->h_tris.assign((const unsigned char *) tris, (const unsigned char *) tris + (size_t) nt * HPT_TRIANGLE_BYTES);
     memset(&s->stats, 0, sizeof s->stats);
     s->stats.bvh_nodes = (uint32_t) hs.nodes.size(); s->stats.bvh_depth = (uint32_t) hs.bvh_depth;
     s->stack_levels = hs.bvh_depth > 0 ? hs.bvh_depth : 1;     // a leaf at depth d has d inner ancestors: at most d pushes
@@ -332,6 +508,7 @@ void hpt_scene_destroy(hpt_scene *s){
     if(s->h_count) hipHostFree(s->h_count);
     hipFree(s->d_local_own); hipFree(s->d_image_own);
     hipFree(s->d_nodes); hipFree(s->d_tris); hipFree(s->d_rounds); hipFree(s->d_mats); hipFree(s->d_lights);
+    free_bdpt(s);
     if(s->ev_start) hipEventDestroy(s->ev_start);
     if(s->ev_stop) hipEventDestroy(s->ev_stop);
     for(hipEvent_t e : s->event_pool) hipEventDestroy(e);
@@ -427,6 +604,71 @@ int hpt_trace_closest(hpt_scene *s, const float *origins, const float *dirs, int
     HIP_TRY(hipMemcpy(prim_out, d_p, (size_t) n * 4, hipMemcpyDeviceToHost));
     hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_p);
     return HPT_OK;
+}
+
+int hpt_scene_set_groups(hpt_scene *s, const int32_t *obj_kind, const int32_t *obj_index, const int32_t *obj_group, int nobj){
+    if(!s) return fail(HPT_ERR_INVALID, "null scene");
+    if(nobj < 0 || (nobj > 0 && (!obj_kind || !obj_index || !obj_group))) return fail(HPT_ERR_INVALID, "bad group arrays");
+    if(nobj != 0 && nobj != s->ns + s->nt) return fail(HPT_ERR_INVALID, "group arrays must list every sphere and triangle once");
+    s->g_kind.assign(obj_kind, obj_kind + nobj); s->g_index.assign(obj_index, obj_index + nobj); s->g_group.assign(obj_group, obj_group + nobj);
+    s->bd_ready = false;
+    return HPT_OK;
+}
+
+int hpt_render_bdpt_device(hpt_scene *scene, const void *camera, int W, int H, int eye_depth, int light_depth, int spp, int spl,
+                           const hpt_params *params, void *d_local, void *hip_stream){
+    return render_bdpt_local(scene, camera, W, H, eye_depth, light_depth, spp, spl, params, (float *) d_local, (hipStream_t) hip_stream);
+}
+
+int hpt_render_bdpt(hpt_scene *s, const void *camera, int W, int H, int eye_depth, int light_depth, int spp, int spl,
+                    const hpt_params *params, float *host_image){
+    if(!s) return fail(HPT_ERR_INVALID, "null scene");
+    if(!host_image) return fail(HPT_ERR_INVALID, "null image");
+    if(params && params->world > 1) return fail(HPT_ERR_INVALID, "hpt_render_bdpt renders the whole image: world must be 0 or 1");
+    Tiling tl;
+    int rc = make_tiling(W, H, params, tl);
+    if(rc) return rc;
+    size_t nloc = (size_t) tl.n_local * 3, nimg = (size_t) W * H * 3;
+    if(nloc > s->cap_local_own){
+        hipFree(s->d_local_own); s->d_local_own = nullptr; s->cap_local_own = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_local_own, nloc * sizeof(float)));
+        s->cap_local_own = nloc;
+    }
+    if(nimg > s->cap_image_own){
+        hipFree(s->d_image_own); s->d_image_own = nullptr; s->cap_image_own = 0;
+        HIP_TRY(hipMalloc((void **) &s->d_image_own, nimg * sizeof(float)));
+        s->cap_image_own = nimg;
+    }
+    hipStream_t st = nullptr;
+    rc = render_bdpt_local(s, camera, W, H, eye_depth, light_depth, spp, spl, params, s->d_local_own, st);
+    if(rc) return rc;
+    launch_untile(st, tl, s->d_local_own, s->d_image_own);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(host_image, s->d_image_own, nimg * sizeof(float), hipMemcpyDeviceToHost));
+    return HPT_OK;
+}
+
+int hpt_bdpt_render_wrapper(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                            const float scene_min[3], const float scene_max[3], const void *camera, float *host_image,
+                            int W, int H, int light_depth, int light_sample, int eye_depth, int spp, int spl, int64_t seed){
+    (void) scene_min; (void) scene_max;
+    // The reference's helper hands over illum / light_sample (src/bdpt_cu_helper.cpp:60-62); the
+    // estimator built here is cpu_bdpt's, which divides by spl itself, so that pre-division is undone.
+    std::vector<unsigned char> L((const unsigned char *) lights, (const unsigned char *) lights + (size_t) std::max(nl, 0) * HPT_LIGHT_BYTES);
+    if(light_sample > 1) for(int i = 0; i < nl; ++i){
+        float *illum = (float *) (L.data() + (size_t) i * HPT_LIGHT_BYTES + 24);
+        for(int c = 0; c < 3; ++c) illum[c] = illum[c] * (float) light_sample;
+    }
+    hpt_scene *s = nullptr;
+    int rc = hpt_scene_create(L.data(), nl, spheres, ns, tris, nt, &s);
+    if(rc) return rc;
+    hpt_params p; memset(&p, 0, sizeof p);
+    p.seed = seed >= 0 ? (uint64_t) seed : (uint64_t) time(nullptr);
+    rc = hpt_render_bdpt(s, camera, W, H, eye_depth, light_depth, spp, spl, &p, host_image);
+    std::string keep = g_err;
+    hpt_scene_destroy(s);
+    g_err = keep;
+    return rc;
 }
 
 int hpt_trace_visibility(hpt_scene *s, const float *p1, const float *p2, int n, int flags, int32_t *vis_out){

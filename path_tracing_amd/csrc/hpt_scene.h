@@ -6,7 +6,7 @@
 //   triangle      48 B  v0 | e1 = v1-v0 | e2 = v2-v0, in BVH leaf order
 //   round prim    32 B  spheres followed by light balls (the reference's scan order)
 //   material      32 B  de-duplicated CudaMaterial records
-//   light         80 B  CudaLight with the per-light invariants hoisted
+//   light        112 B  CudaLight with the per-light invariants hoisted
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -46,17 +46,19 @@ struct DevMaterial {       // 32 B
     float metallic; float eta; uint32_t type; uint32_t pad;
 };
 
-struct DevLight {          // 80 B
+struct DevLight {          // 112 B
     float pos[3]; float r;
     float main_dir[3]; float cos_cutoff;     // normalize(dir); cosf(cutoff) from the host libm
     float neg_dir[3]; float cutoff;          // normalize(dir * -1) for parallel lights
     float illum[3]; float area;              // 4 * pi * r * r
     uint32_t is_parallel; float cone_ratio;  // (1 - cos_cutoff) / 2
     uint32_t pad[2];
+    float raw_dir[3]; uint32_t pad2;         // light.dir as handed over (the BDPT path normalises it itself)
+    float ball_c[3]; uint32_t pad3;          // light_ball.center (equals pos for parsed scenes)
 };
 
 static_assert(sizeof(BvhNode) == 64 && sizeof(DevTriangle) == 48 && sizeof(DevRound) == 32, "layout");
-static_assert(sizeof(DevMaterial) == 32 && sizeof(DevLight) == 80, "layout");
+static_assert(sizeof(DevMaterial) == 32 && sizeof(DevLight) == 112, "layout");
 
 // Host-side flattened scene, ready to upload.
 struct HostScene {
@@ -69,6 +71,35 @@ struct HostScene {
     int bvh_depth = 0;
     double ms_bvh_build = 0.0;
 };
+
+// ---- scene of the bidirectional (cpu_bdpt-estimator) path -------------------------------------
+// The reference's CPU renderer traces a one-level list of groups (reference src/cpu_bdpt.cpp:43-61,
+// src/object.cpp:104-146): a group's box is slab-tested, then its objects are tried in insertion
+// order with an inclusive range, so among equal distances the LAST object wins.  Each group gets
+// its own BVH here; `ordinal` of a triangle / `pad[0]` of a sphere hold that iteration order.
+struct DevGroup {          // 48 B
+    float mn[3]; uint32_t root;            // child code of the group's BVH (leaf, inner or kEmptyChild)
+    float mx[3]; uint32_t sphere_first;
+    uint32_t sphere_count; uint32_t pad[3];
+};
+static_assert(sizeof(DevGroup) == 48, "layout");
+
+struct HostBdptScene {
+    std::vector<BvhNode> nodes;
+    std::vector<DevTriangle> tris;       // leaf order per group
+    std::vector<DevRound> spheres;       // grouped, insertion order inside a group
+    std::vector<DevGroup> groups;        // map order
+    std::vector<DevMaterial> materials;
+    std::vector<DevLight> lights;
+    float scene_min[3], scene_max[3];    // union of the group boxes (parallel-light emission)
+    int bvh_depth = 0;
+};
+
+// obj_kind[i] (0 sphere, 1 triangle), obj_index[i] (into spheres / tris), obj_group[i]: the scene
+// file's objects in insertion order; null arrays = one group holding the spheres then the triangles.
+const char *build_bdpt_host_scene(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                                  const int32_t *obj_kind, const int32_t *obj_index, const int32_t *obj_group, int nobj,
+                                  HostBdptScene &out);
 
 // Flattens reference records (layouts in include/hpt.h) and builds the BVH.
 // Returns an empty string on success, an error message otherwise.

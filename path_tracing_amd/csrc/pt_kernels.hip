@@ -307,7 +307,7 @@ void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue, co
 }
 
 constexpr int kLdsMats = 256;    // material records staged in LDS (8 KiB)
-constexpr int kLdsLights = 64;   // light records staged in LDS (5 KiB)
+constexpr int kLdsLights = 64;   // light records staged in LDS (7 KiB)
 constexpr int kShadeChunk = 2048;        // paths per workgroup at most (LDS staging capacity)
 constexpr int kShadeTargetGroups = 1024; // workgroups a short queue is spread over
 
@@ -332,7 +332,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     }
     if(lights_in_lds){
         const uint32_t *src = (const uint32_t *) sc.lights; uint32_t *dst = (uint32_t *) s_lights;
-        for(int w = threadIdx.x; w < sc.num_lights * 20; w += kBlock) dst[w] = src[w];
+        for(int w = threadIdx.x; w < sc.num_lights * (int) (sizeof(DevLight) / 4); w += kBlock) dst[w] = src[w];
     }
     __syncthreads();
     const DevMaterial *mats = mats_in_lds ? s_mats : sc.mats;

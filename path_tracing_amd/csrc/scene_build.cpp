@@ -53,6 +53,7 @@ struct Builder {
     float pad_abs = 0.0f;
     int max_depth_seen = 0;
     int max_leaf = kMaxLeafTris;
+    uint32_t node_base = 0, tri_base = 0;     // offsets when several BVHs share one node / triangle array
 
     static constexpr int kBins = 16;
 
@@ -68,7 +69,7 @@ struct Builder {
     }
 
     uint32_t make_leaf(int first, int count){
-        uint32_t start = (uint32_t) order.size();
+        uint32_t start = (uint32_t) order.size() + tri_base;
         for(int i = 0; i < count; ++i) order.push_back(prims[first + i].index);
         return kLeafFlag | (start << 3) | (uint32_t) (count - 1);
     }
@@ -144,6 +145,7 @@ struct Builder {
 
         uint32_t me = (uint32_t) nodes.size();
         nodes.emplace_back();
+        // (children return codes that already include node_base / tri_base)
         Box lb, rb;
         uint32_t lc = build(first, mid - first, depth + 1, lb);
         uint32_t rc = build(mid, first + count - mid, depth + 1, rb);
@@ -151,7 +153,7 @@ struct Builder {
         write_box(n.lmin, n.lmax, lb); n.left = lc;
         write_box(n.rmin, n.rmax, rb); n.right = rc;
         n.pad0 = n.pad1 = 0;
-        return me;
+        return me + node_base;
     }
 };
 
@@ -220,6 +222,8 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
     for(int i = 0; i < nl; ++i){
         const RefLight &L = lights[i];
         DevLight d; memset(&d, 0, sizeof d);
+        d.raw_dir[0] = L.dir[0]; d.raw_dir[1] = L.dir[1]; d.raw_dir[2] = L.dir[2];
+        d.ball_c[0] = L.ball.c[0]; d.ball_c[1] = L.ball.c[1]; d.ball_c[2] = L.ball.c[2];
         d.pos[0] = L.pos[0]; d.pos[1] = L.pos[1]; d.pos[2] = L.pos[2];
         d.r = L.ball.r;
         normalize3(L.dir, 1.0f, d.main_dir);          // normalize(light.dir), pt_cu.cu:75,167
@@ -292,6 +296,119 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
     auto t1 = std::chrono::steady_clock::now();
     hs.ms_bvh_build = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if(hs.materials.empty()){ DevMaterial m; memset(&m, 0, sizeof m); hs.materials.push_back(m); }
+    return "";
+}
+
+
+const char *build_bdpt_host_scene(const void *lights_v, int nl, const void *spheres_v, int ns, const void *tris_v, int nt,
+                                  const int32_t *obj_kind, const int32_t *obj_index, const int32_t *obj_group, int nobj,
+                                  HostBdptScene &out){
+    if(nl < 0 || ns < 0 || nt < 0) return "negative primitive count";
+    if((nl > 0 && !lights_v) || (ns > 0 && !spheres_v) || (nt > 0 && !tris_v)) return "null primitive array";
+    const RefSphere *spheres = (const RefSphere *) spheres_v;
+    const RefTriangle *tris = (const RefTriangle *) tris_v;
+    out = HostBdptScene();
+    {   // the light records are the PT path's
+        HostScene tmp;
+        const char *e = build_host_scene(lights_v, nl, nullptr, 0, nullptr, 0, tmp);
+        if(e && *e) return e;
+        out.lights = tmp.lights;
+    }
+    struct Item { int kind, index; uint32_t seq; };
+    std::map<int, std::vector<Item>> gm;
+    uint32_t seq = 0;
+    if(obj_kind && obj_index && obj_group){
+        // sequence numbers follow the CPU renderer's iteration order: groups in map order, objects in insertion order
+        for(int i = 0; i < nobj; ++i){
+            if(obj_kind[i] == 0 ? (obj_index[i] < 0 || obj_index[i] >= ns) : (obj_index[i] < 0 || obj_index[i] >= nt)) return "object index out of range";
+            gm[obj_group[i]].push_back(Item{ obj_kind[i], obj_index[i], 0u });
+        }
+    } else {
+        for(int i = 0; i < ns; ++i) gm[0].push_back(Item{ 0, i, 0u });
+        for(int i = 0; i < nt; ++i) gm[0].push_back(Item{ 1, i, 0u });
+    }
+    for(auto &kv : gm) for(Item &it : kv.second) it.seq = seq++;
+
+    std::map<MatKey, uint32_t> mat_table;
+    Box scene_box; scene_box.reset();
+    std::vector<Box> gboxes;
+    for(auto &kv : gm){
+        Box gb; for(int a = 0; a < 3; ++a){ gb.mn[a] = 99999.f; gb.mx[a] = -99999.f; }       // AABB::add_obj, src/object.cpp:123-146
+        for(const Item &it : kv.second){
+            if(it.kind == 0){
+                const RefSphere &s = spheres[it.index];
+                for(int a = 0; a < 3; ++a){
+                    gb.mn[a] = std::min({ gb.mn[a], s.c[a] + s.r, s.c[a] - s.r });
+                    gb.mx[a] = std::max({ gb.mx[a], s.c[a] + s.r, s.c[a] - s.r });
+                }
+            } else {
+                const RefTriangle &t = tris[it.index];
+                const float *vv[3] = { t.v0, t.v1, t.v2 };
+                for(int k = 0; k < 3; ++k) for(int a = 0; a < 3; ++a){ gb.mn[a] = std::min(gb.mn[a], vv[k][a]); gb.mx[a] = std::max(gb.mx[a], vv[k][a]); }
+            }
+        }
+        // AABB::intersectAABB widens a degenerate axis in place every time it is called
+        // (src/object.cpp:108-111); the box it settles on is used from the start here
+        for(int a = 0; a < 3; ++a) for(int guard = 0; guard < 64 && gb.mx[a] - gb.mn[a] < 1e-6f; ++guard){ gb.mn[a] -= 0.5f * 1e-6f; gb.mx[a] += 0.5f * 1e-6f; }
+        gboxes.push_back(gb);
+        scene_box.grow(gb);
+    }
+    for(int a = 0; a < 3; ++a){ out.scene_min[a] = 1e9f; out.scene_max[a] = -1e9f; }
+    for(const Box &gb : gboxes) for(int a = 0; a < 3; ++a){ out.scene_min[a] = std::min(out.scene_min[a], gb.mn[a]); out.scene_max[a] = std::max(out.scene_max[a], gb.mx[a]); }
+    float extent = 0.0f;
+    if(!gboxes.empty()) for(int a = 0; a < 3; ++a){
+        extent = std::max(extent, scene_box.mx[a] - scene_box.mn[a]);
+        extent = std::max(extent, std::max(std::fabs(scene_box.mn[a]), std::fabs(scene_box.mx[a])));
+    }
+    size_t gi = 0;
+    for(auto &kv : gm){
+        DevGroup g; memset(&g, 0, sizeof g);
+        for(int a = 0; a < 3; ++a){ g.mn[a] = gboxes[gi].mn[a]; g.mx[a] = gboxes[gi].mx[a]; }
+        g.sphere_first = (uint32_t) out.spheres.size();
+        std::vector<Item> gtris;
+        for(const Item &it : kv.second){
+            if(it.kind == 0){
+                const RefSphere &s = spheres[it.index];
+                DevRound r; memset(&r, 0, sizeof r);
+                r.c[0] = s.c[0]; r.c[1] = s.c[1]; r.c[2] = s.c[2]; r.r = s.r;
+                r.material = intern_material(s.m, mat_table, out.materials);
+                r.flags = (s.m.eta <= 0.0f) ? 1u : 0u;
+                r.pad[0] = it.seq;
+                out.spheres.push_back(r);
+            } else gtris.push_back(it);
+        }
+        g.sphere_count = (uint32_t) out.spheres.size() - g.sphere_first;
+        Builder B;
+        B.node_base = (uint32_t) out.nodes.size(); B.tri_base = (uint32_t) out.tris.size();
+        B.pad_abs = 2e-6f * extent;
+        B.prims.resize(gtris.size());
+        for(size_t i = 0; i < gtris.size(); ++i){
+            const RefTriangle &t = tris[gtris[i].index];
+            Prim &p = B.prims[i];
+            p.box.reset(); p.box.grow(t.v0); p.box.grow(t.v1); p.box.grow(t.v2);
+            for(int a = 0; a < 3; ++a) p.cen[a] = 0.5f * (p.box.mn[a] + p.box.mx[a]);
+            p.index = (uint32_t) i;
+        }
+        if(gtris.empty()) g.root = kEmptyChild;
+        else { Box rb; g.root = B.build(0, (int) gtris.size(), 0, rb); }
+        if(B.max_depth_seen > kMaxBvhDepth) return "internal error: BVH deeper than the traversal stack";
+        out.bvh_depth = std::max(out.bvh_depth, B.max_depth_seen);
+        out.nodes.insert(out.nodes.end(), B.nodes.begin(), B.nodes.end());
+        for(uint32_t oi : B.order){
+            const Item &it = gtris[oi];
+            const RefTriangle &t = tris[it.index];
+            DevTriangle d;
+            for(int a = 0; a < 3; ++a){ d.v0[a] = t.v0[a]; d.e1[a] = t.v1[a] - t.v0[a]; d.e2[a] = t.v2[a] - t.v0[a]; }   // src/object.cpp:75
+            d.ordinal = it.seq;
+            d.material = intern_material(t.m, mat_table, out.materials);
+            d.flags = (t.m.eta <= 0.0f) ? 1u : 0u;
+            out.tris.push_back(d);
+        }
+        out.groups.push_back(g);
+        ++gi;
+    }
+    if(out.materials.empty()){ DevMaterial m; memset(&m, 0, sizeof m); out.materials.push_back(m); }
+    if(out.nodes.empty()){ BvhNode n; memset(&n, 0, sizeof n); out.nodes.push_back(n); }
     return "";
 }
 

@@ -229,15 +229,30 @@ def _cross(a, b):
                      f32(f32(a[0] * b[1]) - f32(a[1] * b[0]))], f32)
 
 
-def make_camera(eye, look_at, view_up, fov_deg: float, W: int, H: int) -> np.ndarray:
+_LIBM = None
+
+
+def _tanf(x: float) -> np.float32:
+    global _LIBM
+    if _LIBM is None:
+        import ctypes
+        import ctypes.util
+        _LIBM = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        _LIBM.tanf.restype = ctypes.c_float
+        _LIBM.tanf.argtypes = [ctypes.c_float]
+    return f32(_LIBM.tanf(float(x)))
+
+
+def make_camera(eye, look_at, view_up, fov_deg: float, W: int, H: int, tan_in_float: bool = False) -> np.ndarray:
     """init_camera (src/main_cli.cpp:25-40): top-left origin, +dy goes down.
-    The reference CLI hard-codes fov 50 (main_cli.cpp:158); cpu_bdpt uses the parsed one."""
+    The reference CLI hard-codes fov 50 (main_cli.cpp:158); cpu_bdpt uses the parsed one and takes
+    the tangent in float (std::tan(float), src/cpu_bdpt.cpp:192): tan_in_float=True."""
     eye = np.asarray(eye, f32)
     look_at = np.asarray(look_at, f32)
     view_up = np.asarray(view_up, f32)
     aspect = f32(f32(W) / f32(H))
     theta = f32(f32(f32(fov_deg) * f32(3.14159265358979323846)) / f32(180.0))
-    half_h = f32(math.tan(float(f32(theta / f32(2.0)))))
+    half_h = _tanf(float(f32(theta / f32(2.0)))) if tan_in_float else f32(math.tan(float(f32(theta / f32(2.0)))))
     half_w = f32(aspect * half_h)
     w = _norm_glm(eye - look_at)
     u = _norm_glm(_cross(view_up, w))
