@@ -39,4 +39,17 @@ void pt_render_wrapper(
     const CudaCamera cuda_camera, float3 *cuda_image, int W, int H,
     int light_depth, int light_sample, int eye_depth, int spp);
 
+
+// Replaces:  void bdpt_render_wrapper(...)   reference include/bdpt_cu.cuh:30-37, defined src/bdpt_cu.cu:538-674
+// The lights arrive with illum / light_sample (reference src/bdpt_cu_helper.cpp:60-62).  The image is the
+// estimator of the reference's CPU renderer run_cpu_bdpt (src/cpu_bdpt.cpp), which the CUDA kernel differs
+// from in the ways listed in SURVEY.md Q19; one implicit group (no grouping crosses this signature).
+void bdpt_render_wrapper(
+    const CudaLight *cuda_lights, int num_lights,
+    const CudaSphere *cuda_spheres, int num_spheres,
+    const CudaTriangle *cuda_triangles, int num_triangles,
+    float3 scene_min, float3 scene_max,
+    const CudaCamera cuda_camera, float3 *cuda_image, int W, int H,
+    int light_depth, int light_sample, int eye_depth, int spp, int spl /*sample per light*/);
+
 #endif

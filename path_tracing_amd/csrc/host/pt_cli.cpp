@@ -4,7 +4,8 @@
 // PNG through zlib instead of OpenCV.  Extra flags the reference lacks:
 //   --width/--height  override the scene's R line        --seed N   reproducible streams
 //   --max-depth N     eye depth (reference: EYE_DEPTH 4)  --obj FILE append an OBJ's faces (current material: 0.7 grey diffuse)
-// Only --mode pt is built (bdpt/ppm are outside this library).
+// --mode pt and --mode bdpt are built (ppm is outside this library); bdpt renders the reference's CPU
+// estimator (run_cpu_bdpt) on the GPU.
 #include "scene_model.hpp"
 #include "../../../include/hpt.h"
 
@@ -42,7 +43,7 @@ int main(int argc, char **argv){
                       << "Options:\n"
                       << "  --spp <int>       Samples per pixel (default: 8)\n"
                       << "  --spl <int>       Samples per light (default: 8)\n"
-                      << "  --mode <string>   Render mode: pt (default: pt)\n"
+                      << "  --mode <string>   Render mode: pt, bdpt (default: pt)\n"
                       << "  --device <string> Compute device: gpu (default: gpu)\n"
                       << "  --output <string> Output image path (.png or .pfm)\n"
                       << "  --input <string>  Input scene file\n"
@@ -61,7 +62,7 @@ int main(int argc, char **argv){
     std::cout << " Input  : " << input_file << "\n";
     std::cout << " Output : " << output_file << "\n";
     std::cout << "====================================\n";
-    if(mode != "pt"){ std::cerr << "[Error] this build provides --mode pt only.\n"; return -1; }
+    if(mode != "pt" && mode != "bdpt"){ std::cerr << "[Error] this build provides --mode pt and --mode bdpt (ppm is outside this library).\n"; return -1; }
 
     hpt_host::SceneFile scene;
     if(!hpt_host::parse_scene_file(input_file, scene)){
@@ -86,12 +87,14 @@ int main(int argc, char **argv){
     std::vector<float3> frame_results((size_t) W * H);
 
     std::cout << "[Init] Transferring Data to the GPU...\n";
-    move_data_to_cuda_pt(scene.groups, scene.lights, spl);
+    if(mode == "bdpt") move_data_to_cuda_bdpt(scene.groups, scene.lights, spl);
+    else move_data_to_cuda_pt(scene.groups, scene.lights, spl);
     if(seed >= 0){ hpt_host::g_seed_from_clock = false; hpt_host::g_run_params.seed = (uint64_t) seed; }
 
     std::cout << "[Render] Starting Render...\n";
     auto start_time = std::chrono::steady_clock::now();
-    run_cuda_pt(cam, frame_results.data(), LIGHT_DEPTH, max_depth, W, H, spp);
+    if(mode == "bdpt") run_cuda_bdpt(cam, frame_results.data(), LIGHT_DEPTH, max_depth, W, H, spp, spl);
+    else run_cuda_pt(cam, frame_results.data(), LIGHT_DEPTH, max_depth, W, H, spp);
     std::cout << "\n";
     auto diff = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start_time);
     std::cout << "[Render] Finished in " << diff.count() << " ms.\n";

@@ -276,6 +276,59 @@ void run_cuda_pt(CudaCamera cam, float3 *image_buffer, int light_depth, int eye_
     if(rc != HPT_OK) std::cerr << "run_cuda_pt: " << hpt_last_error() << std::endl;
 }
 
+namespace bdpt_ns {
+std::vector<CudaSphere> cuda_spheres;
+std::vector<CudaTriangle> cuda_triangles;
+std::vector<CudaLight> cuda_lights;
+int light_sample = 0;
+hpt_scene *scene = nullptr;
+}
+
+void move_data_to_cuda_bdpt(std::map<int, hpt_host::AABB> groups, std::vector<CudaLight> &lights, int light_sample){
+    using namespace hpt_host;
+    bdpt_ns::cuda_spheres.clear(); bdpt_ns::cuda_triangles.clear(); bdpt_ns::cuda_lights.clear();
+    std::vector<int32_t> kind, index, group;
+    for(auto &g : groups){
+        for(Object *obj : g.second.objs){
+            if(const Sphere *sph = dynamic_cast<const Sphere *>(obj)){
+                CudaSphere c; memset(&c, 0, sizeof c);
+                c.center = float3{sph->center.x, sph->center.y, sph->center.z}; c.r = sph->r; c.mtl = to_cmtl(sph->mtl); c.id = sph->obj_id;
+                kind.push_back(0); index.push_back((int32_t) bdpt_ns::cuda_spheres.size()); group.push_back(g.first);
+                bdpt_ns::cuda_spheres.push_back(c);
+            } else if(const Triangle *tri = dynamic_cast<const Triangle *>(obj)){
+                CudaTriangle c; memset(&c, 0, sizeof c);
+                c.v0 = float3{tri->vert[0].x, tri->vert[0].y, tri->vert[0].z}; c.v1 = float3{tri->vert[1].x, tri->vert[1].y, tri->vert[1].z};
+                c.v2 = float3{tri->vert[2].x, tri->vert[2].y, tri->vert[2].z}; c.mtl = to_cmtl(tri->mtl); c.id = tri->obj_id;
+                kind.push_back(1); index.push_back((int32_t) bdpt_ns::cuda_triangles.size()); group.push_back(g.first);
+                bdpt_ns::cuda_triangles.push_back(c);
+            }
+        }
+    }
+    for(auto l : lights){
+        float len = std::sqrt(l.dir.x * l.dir.x + l.dir.y * l.dir.y + l.dir.z * l.dir.z);
+        l.dir = float3{l.dir.x / len, l.dir.y / len, l.dir.z / len};
+        // the reference divides illum by light_sample here (src/bdpt_cu_helper.cpp:60-62) for its CUDA kernel's
+        // light_sample-times larger vertex pool; the estimator behind run_cuda_bdpt is run_cpu_bdpt's, which takes
+        // the undivided flux (src/cpu_bdpt.cpp:255), so the lights are handed over as they are
+        bdpt_ns::cuda_lights.push_back(l);
+    }
+    bdpt_ns::light_sample = light_sample;
+    if(bdpt_ns::scene){ hpt_scene_destroy(bdpt_ns::scene); bdpt_ns::scene = nullptr; }
+    int rc = hpt_scene_create(bdpt_ns::cuda_lights.data(), (int) bdpt_ns::cuda_lights.size(),
+                              bdpt_ns::cuda_spheres.data(), (int) bdpt_ns::cuda_spheres.size(),
+                              bdpt_ns::cuda_triangles.data(), (int) bdpt_ns::cuda_triangles.size(), &bdpt_ns::scene);
+    if(rc == HPT_OK) rc = hpt_scene_set_groups(bdpt_ns::scene, kind.data(), index.data(), group.data(), (int) kind.size());
+    if(rc != HPT_OK){ std::cerr << "move_data_to_cuda_bdpt: " << hpt_last_error() << std::endl; if(bdpt_ns::scene){ hpt_scene_destroy(bdpt_ns::scene); bdpt_ns::scene = nullptr; } }
+}
+
+void run_cuda_bdpt(CudaCamera cam, float3 *image_buffer, int light_depth, int eye_depth, int W, int H, int spp, int spl){
+    if(!bdpt_ns::scene){ std::cerr << "run_cuda_bdpt: no scene moved to the device" << std::endl; return; }
+    hpt_params p = hpt_host::g_run_params;
+    if(hpt_host::g_seed_from_clock) p.seed = (uint64_t) time(nullptr);
+    int rc = hpt_render_bdpt(bdpt_ns::scene, &cam, W, H, eye_depth, light_depth, spp, spl, &p, &image_buffer->x);
+    if(rc != HPT_OK) std::cerr << "run_cuda_bdpt: " << hpt_last_error() << std::endl;
+}
+
 // ---- C entry points for tests (flattening + camera through the C++ mirror) -------------------
 extern "C" {
 int hpt_host_flatten_scene_file(const char *path, int *nl, int *ns, int *nt, const void **lights, const void **spheres,

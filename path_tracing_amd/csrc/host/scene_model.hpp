@@ -82,3 +82,7 @@ bool write_image(const std::string &path, const float3 *linear_rgb, int W, int H
 // instead of appending to it (the reference's pt_ns vectors are never cleared).
 void move_data_to_cuda_pt(std::map<int, hpt_host::AABB> groups, std::vector<CudaLight> &cuda_lights, int light_sample);
 void run_cuda_pt(CudaCamera cam, float3 *image_buffer, int light_depth, int eye_depth, int W, int H, int spp);
+// BDPT twins (include/bdpt_cu_helper.h:5-6, src/bdpt_cu_helper.cpp:13-81); the scene file's grouping is kept
+// and handed to the device scene, so the result is run_cpu_bdpt's estimator on the same groups.
+void move_data_to_cuda_bdpt(std::map<int, hpt_host::AABB> groups, std::vector<CudaLight> &cuda_lights, int light_sample);
+void run_cuda_bdpt(CudaCamera cam, float3 *image_buffer, int light_depth, int eye_depth, int W, int H, int spp, int spl = 1);

@@ -98,3 +98,5 @@ def test_reference_named_adapter_exports_the_reference_symbol(tmp_path):
     assert wanted == [REF_SYMBOL]
     defined = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
     assert REF_SYMBOL in defined
+    # bdpt_render_wrapper (reference include/bdpt_cu.cuh:30-37): same argument list plus the trailing spl
+    assert "_Z19bdpt_render_wrapperPK9CudaLightiPK10CudaSphereiPK12CudaTrianglei6float3S8_10CudaCameraPS8_iiiiiii" in defined

@@ -272,3 +272,73 @@ def test_reference_named_cpp_entry_point(hpt, sio, input_scene, oracle_mod, monk
        img.ctypes.data, W, H, 4, 8, 4, 3)
     ref, _ = oracle_mod.pt_render(L, sp, tr, cam, W, H, 4, 3, seed=41)
     assert_parity(img, ref)
+
+
+# ---- bidirectional estimator (config 1 / config 4; oracle: oracle/bdpt_oracle.cpp, which replays the reference's
+# ---- own cpu_bdpt.cpp image bit for bit -- tests/test_bdpt_oracle.py) ---------------------------------------------
+
+def _bdpt_case(sio, oracle_mod, name):
+    sc = sio.load_scene(os.path.join(GOLDEN, "scenes", name + ".txt"))
+    L, sp, tr = sio.flatten_for_pt(sc)
+    return sc, L, sp, tr, oracle_mod.object_order(sc)
+
+
+@pytest.mark.parametrize("name,W,H,spp,spl,depth", [
+    ("input", 96, 64, 3, 8, 4),        # config 1 scene: glass, mirror, conductors, 4 cone lights, 2 groups
+    ("input", 33, 21, 2, 3, 6),
+    ("mis_test", 64, 64, 4, 8, 4),     # config 4 scene (degenerate: cos(360 deg) = 1 rejects the cone test)
+])
+def test_bdpt_gpu_matches_cpu_bdpt_oracle(hpt, sio, oracle_mod, name, W, H, spp, spl, depth):
+    sc, L, sp, tr, order = _bdpt_case(sio, oracle_mod, name)
+    ref, st = oracle_mod.bdpt_render(L, sp, tr, order, sc.eye, sc.look_at, sc.view_up, sc.fov, W, H, depth, depth, spp, spl, seed=8)
+    cam = sio.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, W, H, tan_in_float=True)
+    with hpt.Scene(L, sp, tr) as scene:
+        scene.set_groups(*order)
+        img = scene.render_bdpt(cam, W, H, depth, depth, spp, spl, hpt.make_params(seed=8))
+        img2 = scene.render_bdpt(cam, W, H, depth, depth, spp, spl, hpt.make_params(seed=8, samples_per_pass=1, tile=8))
+    assert_parity(img, ref)
+    assert np.array_equal(img, img2)
+
+
+def test_bdpt_config1_full_size(hpt, sio, oracle_mod):
+    """BASELINE config 1: input.txt, 256 x 256, 4 spp (spl 8, depth 4/4) -- GPU vs the cpu_bdpt oracle."""
+    sc, L, sp, tr, order = _bdpt_case(sio, oracle_mod, "input")
+    ref, st = oracle_mod.bdpt_render(L, sp, tr, order, sc.eye, sc.look_at, sc.view_up, sc.fov, 256, 256, 4, 4, 4, 8, seed=1)
+    cam = sio.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, 256, 256, tan_in_float=True)
+    with hpt.Scene(L, sp, tr) as scene:
+        scene.set_groups(*order)
+        img = scene.render_bdpt(cam, 256, 256, 4, 4, 4, 8, hpt.make_params(seed=1))
+    assert_parity(img, ref)
+    assert st["shadow_rays"] > 100 * st["samples"]
+
+
+def test_bdpt_synthetic_scene_and_ties(hpt, sio, oracle_mod):
+    # single implicit group (spheres then triangles), coincident triangles: the CPU loop keeps the LAST of equal hits
+    L, sp, tr = sio.cornell_with_sphere(1500)
+    dup = tr[:12].copy(); dup["mtl"]["base_color"] = (0.1, 0.8, 0.1)
+    tr = np.concatenate([tr, dup])
+    order = oracle_mod.object_order(None, sp, tr)
+    ref, _ = oracle_mod.bdpt_render(L, sp, tr, order, sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 48, 48, 4, 4, 2, 4, seed=3)
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 48, 48, tan_in_float=True)
+    with hpt.Scene(L, sp, tr) as scene:
+        img = scene.render_bdpt(cam, 48, 48, 4, 4, 2, 4, hpt.make_params(seed=3))
+    assert_parity(img, ref)
+
+
+def test_bdpt_no_lights_and_one_shot_wrapper(hpt, sio, oracle_mod):
+    from path_tracing_amd.layouts import LIGHT
+    sc, L, sp, tr, order = _bdpt_case(sio, oracle_mod, "input")
+    cam = sio.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, 24, 24, tan_in_float=True)
+    with hpt.Scene(np.zeros(0, LIGHT), sp, tr) as scene:
+        assert not scene.render_bdpt(cam, 24, 24, 4, 4, 2, 2).any()            # src/cpu_bdpt.cpp:178
+    # reference wrapper argument list: illum arrives divided by light_sample (src/bdpt_cu_helper.cpp:60-62)
+    lib = hpt.load_library()
+    L8 = L.copy(); L8["illum"] = L["illum"] / np.float32(8)
+    img = np.empty((24, 24, 3), np.float32)
+    z3 = (C.c_float * 3)()
+    rc = lib.hpt_bdpt_render_wrapper(L8.ctypes.data_as(C.c_void_p), len(L8), sp.ctypes.data_as(C.c_void_p), len(sp),
+                                     tr.ctypes.data_as(C.c_void_p), len(tr), z3, z3, np.ascontiguousarray(cam).ctypes.data_as(C.c_void_p),
+                                     img.ctypes.data_as(C.c_void_p), 24, 24, 4, 8, 4, 2, 8, C.c_int64(6))
+    assert rc == 0
+    ref, _ = oracle_mod.bdpt_render(L, sp, tr, oracle_mod.object_order(None, sp, tr), sc.eye, sc.look_at, sc.view_up, sc.fov, 24, 24, 4, 4, 2, 8, seed=6)
+    assert_parity(img, ref)
