@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--tris", type=int, default=100_000)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on a one-GPU box)")
     ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
     args = ap.parse_args()
 
@@ -87,9 +88,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    device_index = local_rank % ndev              # one GPU per rank; ranks share a GPU only in the gloo rehearsal
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     W = H = args.size
     lights, spheres, tris = scene_io.cornell_with_sphere(args.tris)
@@ -132,7 +140,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -171,7 +179,7 @@ def main():
             "config": {"workload": "configs[2]: unidirectional PT + NEE, Cornell-style box + tessellated sphere, "
                                    "%d triangles behind a BVH, %dx%d, %d spp, depth %d, 1 cone light"
                                    % (len(tris), W, H, args.spp, args.depth),
-                       "parallelism": "image tiles 32x32 round-robin over %d rank(s), RCCL gather to rank 0" % world,
+                       "parallelism": "image tiles 32x32 round-robin over %d rank(s), %s gather to rank 0" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "seed": 1},
             "roofline": {"bound": "hbm", "kernel": "k_trace (closest-hit + any-hit BVH traversal)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

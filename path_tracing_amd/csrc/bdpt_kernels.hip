@@ -260,13 +260,13 @@ HPT_DEV BdHit bd_resolve(const BdptSceneDev &sc, f3 ro, f3 rd, float t, uint32_t
 HPT_DEV f3 bsdf_value(const Mat &m, f3 wo_w, f3 wi_w, f3 N){
     ShadeCtx c = make_shade_ctx(N, wo_w);
     f3 f; float pdf;
-    bsdf_eval_pdf(m, c, wi_w, f, pdf);
+    bsdf_eval_pdf<true, false>(m, c, wi_w, f, pdf);
     return f;
 }
 HPT_DEV float bsdf_pdf_only(const Mat &m, f3 wo_w, f3 wi_w, f3 N){
     ShadeCtx c = make_shade_ctx(N, wo_w);
     f3 f; float pdf;
-    bsdf_eval_pdf(m, c, wi_w, f, pdf);
+    bsdf_eval_pdf<false, true>(m, c, wi_w, f, pdf);
     return pdf;
 }
 
@@ -579,65 +579,98 @@ HPT_DEV float bd_mis_weight(const BdptPathBuf &bp, uint32_t path, uint32_t slots
     return 1.0f / sum_ratios;
 }
 
-// connection loop body, src/cpu_bdpt.cpp:389-439: one wave = one eye vertex x 64 light vertices
+// connection loop body, src/cpu_bdpt.cpp:389-439.  A workgroup takes 4 (eye vertex, 64 light vertices)
+// tiles = 256 candidate pairs.  Phase 1: every lane runs the cheap culls of its pair (zero throughput,
+// distance, both cosines, emission cone) and the survivors are compacted into an LDS list (ballot +
+// mbcnt); culled pairs get their zero written at once.  Phase 2: the expensive part -- two BSDF values,
+// the shadow ray, the MIS weight -- runs over the dense survivor list, so its lanes are all busy.
 __global__ __launch_bounds__(kBlock)
 void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lvs, int n_lv, int light_depth,
                     const uint32_t *cqueue, const uint32_t *ccount, float ex, float ey, float ez, uint32_t slots){
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    __shared__ uint32_t s_pair_path[kBlock];
+    __shared__ uint32_t s_pair_j[kBlock];
+    __shared__ uint32_t s_n;
     uint32_t *stk = s_stack + threadIdx.x;
     uint32_t count = *ccount;
     uint32_t chunks = ((uint32_t) n_lv + 63u) / 64u;
     unsigned long long items = (unsigned long long) count * chunks;
     uint32_t wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     f3 cam_eye = mk3(ex, ey, ez);
-    for(unsigned long long w = (unsigned long long) blockIdx.x * (kBlock / 64) + wave_in_block; w < items;
-        w += (unsigned long long) gridDim.x * (kBlock / 64)){
-        uint32_t path = cqueue[(uint32_t) (w / chunks)];
-        int j = (int) ((uint32_t) (w % chunks) * 64u + lane);
-        float4 vp = bp.vtx_pos[path], vn = bp.vtx_nrm[path], vt = bp.vtx_thr[path], vw = bp.vtx_wo[path];
-        float4 vb = bp.vtx_base[path];
-        f3 contrib = mk3(0, 0, 0);
-        if(j < n_lv){
+    unsigned long long groups = (items + 3ull) / 4ull;
+    for(unsigned long long gidx = blockIdx.x; gidx < groups; gidx += gridDim.x){
+        if(threadIdx.x == 0) s_n = 0u;
+        __syncthreads();
+        // ---- phase 1: culls ----
+        unsigned long long w = gidx * 4ull + wave_in_block;
+        bool survive = false;
+        uint32_t path = 0u; int j = 0;
+        if(w < items){
+            path = cqueue[(uint32_t) (w / chunks)];
+            j = (int) ((uint32_t) (w % chunks) * 64u + lane);
+            if(j < n_lv){
+                float4 vp = bp.vtx_pos[path], vn = bp.vtx_nrm[path];
+                const LightVertexDev *lv = lvs + j;
+                f3 lthr = ld3(lv->thr);
+                bool ok = !(length3(lthr) < 1e-6f);
+                f3 d_vec = ld3(lv->pos) - xyz(vp);
+                float dist2 = dot3(d_vec, d_vec);
+                ok = ok && !(dist2 < 1e-6f);
+                float dist = sqrtf(dist2);
+                f3 wi = d_vec / dist;
+                float cosE = fmaxf(0.0f, dot3(xyz(vn), wi));
+                float cosL = fmaxf(0.0f, dot3(ld3(lv->normal), wi * -1.0f));
+                ok = ok && !(cosE <= 0.0f || cosL <= 0.0f);
+                uint32_t lflags = lv->flags;
+                if(ok && (lflags & 1u) && lv->source_cutoff > 0.0f && !(lflags & 2u)){
+                    int real_light = (j / light_depth) % sc.num_lights;
+                    const DevLight &L = sc.lights[real_light];
+                    f3 light_dir = normalize3(ld3(L.raw_dir));
+                    if(dot3(light_dir, wi * -1.0f) < L.cos_cutoff) ok = false;
+                }
+                survive = ok;
+                if(!ok) bp.contrib[(size_t) path * n_lv + j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        uint32_t pos = lds_push(survive, &s_n);
+        if(survive){ s_pair_path[pos] = path; s_pair_j[pos] = (uint32_t) j; }
+        __syncthreads();
+        // ---- phase 2: dense evaluation of the survivors ----
+        uint32_t n = s_n;
+        if(threadIdx.x < n){
+            path = s_pair_path[threadIdx.x]; j = (int) s_pair_j[threadIdx.x];
+            float4 vp = bp.vtx_pos[path], vn = bp.vtx_nrm[path], vt = bp.vtx_thr[path], vw = bp.vtx_wo[path], vb = bp.vtx_base[path];
             const LightVertexDev lv = lvs[j];
             f3 v_pos = xyz(vp), v_n = xyz(vn), v_thr = xyz(vt), wo_e = xyz(vw);
             Mat vm; vm.base = xyz(vb); vm.roughness = vp.w; vm.metallic = vn.w; vm.eta = vt.w;
             int depth = (int) f2u(vw.w);
             f3 lthr = ld3(lv.thr);
-            bool ok = !(length3(lthr) < 1e-6f);
             f3 d_vec = ld3(lv.pos) - v_pos;
             float dist2 = dot3(d_vec, d_vec);
-            ok = ok && !(dist2 < 1e-6f);
             float dist = sqrtf(dist2);
             f3 wi = d_vec / dist;
             float cosE = fmaxf(0.0f, dot3(v_n, wi));
             float cosL = fmaxf(0.0f, dot3(ld3(lv.normal), wi * -1.0f));
-            ok = ok && !(cosE <= 0.0f || cosL <= 0.0f);
             int t_idx = j % light_depth;
-            if(ok && (lv.flags & 1u) && lv.source_cutoff > 0.0f && !(lv.flags & 2u)){
-                int real_light = (j / light_depth) % sc.num_lights;
-                const DevLight &L = sc.lights[real_light];
-                f3 light_dir = normalize3(ld3(L.raw_dir));
-                if(dot3(light_dir, wi * -1.0f) < L.cos_cutoff) ok = false;
+            f3 contrib = mk3(0, 0, 0);
+            f3 fE = bsdf_value(vm, wo_e, wi, v_n);
+            f3 fL = mk3(1.0f, 1.0f, 1.0f);
+            if(!(lv.flags & 1u) && t_idx > 0){
+                f3 prev = ld3(lvs[j - 1].pos);
+                f3 wo_l = normalize3(prev - ld3(lv.pos));
+                fL = bsdf_value(lv_mat(lv), wo_l, wi * -1.0f, ld3(lv.normal));
             }
-            if(ok){
-                f3 fE = bsdf_value(vm, wo_e, wi, v_n);
-                f3 fL = mk3(1.0f, 1.0f, 1.0f);
-                if(!(lv.flags & 1u) && t_idx > 0){
-                    f3 prev = ld3(lvs[j - 1].pos);
-                    f3 wo_l = normalize3(prev - ld3(lv.pos));
-                    fL = bsdf_value(lv_mat(lv), wo_l, wi * -1.0f, ld3(lv.normal));
-                }
-                if((fE.x <= 0.0f && fE.y <= 0.0f && fE.z <= 0.0f) || (fL.x <= 0.0f && fL.y <= 0.0f && fL.z <= 0.0f)) ok = false;
-                if(ok && bd_visible(sc, v_pos + v_n * kEps, ld3(lv.pos) + ld3(lv.normal) * kEps, stk)){
-                    float G = (cosE * cosL) / fmaxf(dist2, 1e-4f);
-                    const LightVertexDev *lp_base = lvs + (size_t) (j / light_depth) * light_depth;
-                    float mis_w = bd_mis_weight(bp, path, slots, depth, v_pos, v_n, vm, lp_base, t_idx, d_vec, dist2, cam_eye);
-                    f3 c = v_thr * fE * G * fL * lthr * mk3(1.0f, 1.0f, 1.0f) * mis_w;
-                    if(is_valid_color(c)) contrib = clamp_radiance(c, 15.0f);
-                }
+            bool ok = !((fE.x <= 0.0f && fE.y <= 0.0f && fE.z <= 0.0f) || (fL.x <= 0.0f && fL.y <= 0.0f && fL.z <= 0.0f));
+            if(ok && bd_visible(sc, v_pos + v_n * kEps, ld3(lv.pos) + ld3(lv.normal) * kEps, stk)){
+                float G = (cosE * cosL) / fmaxf(dist2, 1e-4f);
+                const LightVertexDev *lp_base = lvs + (size_t) (j / light_depth) * light_depth;
+                float mis_w = bd_mis_weight(bp, path, slots, depth, v_pos, v_n, vm, lp_base, t_idx, d_vec, dist2, cam_eye);
+                f3 c = v_thr * fE * G * fL * lthr * mk3(1.0f, 1.0f, 1.0f) * mis_w;
+                if(is_valid_color(c)) contrib = clamp_radiance(c, 15.0f);
             }
             bp.contrib[(size_t) path * n_lv + j] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
         }
+        __syncthreads();
     }
 }
 
@@ -695,7 +728,7 @@ void launch_bdpt_connect(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, Bdpt
     unsigned long long waves = (unsigned long long) max_items * (((unsigned) n_lv + 63u) / 64u);
     unsigned long long g = (waves + (kBlock / 64) - 1) / (kBlock / 64);
     if(g < 1ull) g = 1ull;
-    if(g > 8192ull) g = 8192ull;
+    if(g > 16384ull) g = 16384ull;
     hipLaunchKernelGGL(k_bdpt_connect, dim3((uint32_t) g), dim3(kBlock), 0, s, sc, pb, bp, lv, n_lv, light_depth, cqueue, ccount,
                        eye[0], eye[1], eye[2], slots);
 }

@@ -432,7 +432,8 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
                                      s->cqueue, &ccnt[ci], eye_depth, P.max_delta, (uint32_t) slots); }
                 { LaunchTimer t(s, stream, timek, 2);
                   launch_bdpt_connect(stream, s->bd, s->pb, s->bp, s->d_lv, n_lv, light_depth, s->cqueue, &ccnt[ci], nslots,
-                                      cam.eye, (uint32_t) slots);
+                                      cam.eye, (uint32_t) slots); }
+                { LaunchTimer t(s, stream, timek, 3);
                   launch_bdpt_reduce(stream, s->pb, s->bp, n_lv, s->cqueue, &ccnt[ci], nslots); }
                 cur ^= 1;
             }

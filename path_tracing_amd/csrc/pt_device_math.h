@@ -175,12 +175,14 @@ HPT_DEV ShadeCtx make_shade_ctx(f3 N, f3 wo_w){
 
 // BSDF value and pdf in one pass over the shared terms (the two reference functions,
 // geometric.cuh:419-456 and 458-484, build the same half vector, D and Lambda(wo)).
+template <bool WANT_F = true, bool WANT_PDF = true>
 HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, float &pdf_out){
     f3 wo = c.wo;
     f3 wi = to_local(wi_w, c.T, c.B, c.N);
     f_out = mk3(0, 0, 0); pdf_out = 0.0f;
-    bool eval_zero = (wo.z == 0.0f || wi.z == 0.0f);
-    bool pdf_zero = (wo.z * wi.z <= 0.0f);
+    bool eval_zero = !WANT_F || (wo.z == 0.0f || wi.z == 0.0f);
+    bool pdf_zero = !WANT_PDF || (wo.z * wi.z <= 0.0f);
+    if(eval_zero && pdf_zero) return;
     if(m.eta > 0.0f && m.roughness < 0.001f) return;
     float alpha = roughness_to_alpha(m.roughness);
     f3 whv = wo + wi;
@@ -190,7 +192,7 @@ HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, 
     float D = ggx_D(wh, alpha);
     float lam_o = ggx_lambda(wo, alpha);
     float awo = fabsf(wo.z), awi = fabsf(wi.z);
-    if(!eval_zero){
+    if(WANT_F && !eval_zero){
         f3 diffuse = m.base / kPi * (1.0f - m.metallic);
         if(wo.z * wi.z < 0.0f) diffuse = mk3(0, 0, 0);
         float G = 1.0f / (1.0f + lam_o + ggx_lambda(wi, alpha));
@@ -200,7 +202,7 @@ HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, 
         f3 specular = (F * D * G) / fmaxf(4.0f * awo * awi, 1e-4f);
         f_out = (wo.z * wi.z > 0.0f) ? diffuse + specular : diffuse;
     }
-    if(!pdf_zero){
+    if(WANT_PDF && !pdf_zero){
         float pdf_diffuse = awi / kPi;
         float G1 = 1.0f / (1.0f + lam_o);
         float pdf_wh = D * G1 * fmaxf(0.0f, dot3(wo, wh)) / awo;

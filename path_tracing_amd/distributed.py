@@ -17,6 +17,15 @@ def gather_framebuffer(local: torch.Tensor, rank: int, world: int, root: int = 0
     [world, n_local, 3] tensor laid out [rank][local slot]; None elsewhere."""
     if world == 1:
         return local.unsqueeze(0)
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        # rehearsal on a one-GPU box: gloo moves host memory
+        host = local.cpu()
+        if rank == root:
+            out = torch.empty((world,) + tuple(host.shape), dtype=host.dtype)
+            dist.gather(host, list(out.unbind(0)), dst=root)
+            return out.to(local.device)
+        dist.gather(host, None, dst=root)
+        return None
     if rank == root:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         dist.gather(local, list(out.unbind(0)), dst=root)
