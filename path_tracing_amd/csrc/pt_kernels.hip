@@ -610,11 +610,13 @@ void k_untile(Tiling tl, const float *gathered, float *image){
 // a launch to a few workgroups); refill threshold 8 -> 51.0, 16 -> 49.6, 32 -> 48.6, 48 -> 48.0.
 constexpr int kTraceChunk = 512;      // rays per workgroup
 constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
+constexpr int kNodeMin = 4;           // fewer lanes than this still walking nodes (while others hold leaves): do the leaves first
+                                      // (A/B: off 42.1 ms, 2: 39.9, 4: 39.4, 8: 40.2, 16: 41.3, 32: 43.2)
 constexpr uint32_t kTraceShortQueue = 1u << 20;   // below this many rays a workgroup takes 256 instead of kTraceChunk
 
 template <bool ANY, bool COUNT>
 HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *queue,
-                         uint32_t end, uint32_t *stk, uint32_t *s_next, int refill_min, WorkCounters *wc){
+                         uint32_t end, uint32_t *stk, uint32_t *s_next, int refill_min, int node_min, WorkCounters *wc){
     bool active = false, exhausted = false;
     uint32_t path = 0u, cur = 0u;
     int sp = 0;
@@ -686,8 +688,14 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
         } else if(idle == ~0ull){
             break;                                      // chunk exhausted and every ray finished
         }
-        // phase 1: walk inner nodes until this lane holds a leaf (or its ray is finished)
+        const unsigned long long idle_at_entry = __ballot(!active);
+        // phase 1: walk inner nodes until this lane holds a leaf (or its ray is finished); when only a
+        // few lanes are still descending while others wait with a leaf, go and do the leaves first
         while(active && !(cur & kLeafFlag)){
+            if(node_min > 0){
+                unsigned long long walking = __ballot(true);
+                if(__popcll(walking) < node_min && __popcll(walking) < 64 - (int) __popcll(idle_at_entry)) break;
+            }
             if(COUNT){
                 n_lane_steps += 1; n_boxes += 2;
                 if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_wave_steps += 64;   // one wave trip
@@ -726,8 +734,8 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                 }
             }
         }
-        // phase 2: the leaf
-        if(active){
+        // phase 2: the leaf (lanes that left phase 1 early still hold an inner node and skip it)
+        if(active && (cur & kLeafFlag)){
             if(COUNT){
                 n_leaf_lane += 1;
                 if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_leaf_wave += 64;
@@ -787,7 +795,7 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock)
 void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, const uint32_t *ecount_ptr,
-             const uint32_t *squeue, const uint32_t *scount_ptr, uint32_t chunk_rays, int refill_min, WorkCounters *wc){
+             const uint32_t *squeue, const uint32_t *scount_ptr, uint32_t chunk_rays, int refill_min, int node_min, WorkCounters *wc){
     extern __shared__ uint32_t s_dyn_stack[];        // [stack level][lane], sized by the BVH depth
     __shared__ uint32_t s_next;
     uint32_t ecount = ecount_ptr ? *ecount_ptr : 0u, scount = scount_ptr ? *scount_ptr : 0u;
@@ -805,8 +813,8 @@ void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, cons
     uint32_t end = begin + csize < total ? begin + csize : total;
     if(threadIdx.x == 0) s_next = begin;
     __syncthreads();
-    if(shadow) trace_chunk<true, COUNT>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, wc);
-    else trace_chunk<false, COUNT>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, wc);
+    if(shadow) trace_chunk<true, COUNT>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc);
+    else trace_chunk<false, COUNT>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc);
 }
 
 template <bool BRUTE>
@@ -896,6 +904,8 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
                   uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc){
     uint32_t chunk = ((tuning >> 16) & 0xFF) ? (uint32_t) ((tuning >> 16) & 0xFF) * 256u : (uint32_t) kTraceChunk;
     int refill_min = ((tuning >> 8) & 0xFF) ? ((tuning >> 8) & 0xFF) : kRefillMin;
+    int node_min = ((tuning >> 24) & 0x7F) ? ((tuning >> 24) & 0x7F) : kNodeMin;
+    if(node_min == 0x7F) node_min = 0;                 // tuning: switch the early leaf break off
     // worst-case grid for either chunking regime of k_trace (long queues: `chunk` rays per workgroup,
     // queues shorter than kTraceShortQueue: kBlock rays per workgroup)
     auto groups = [&](uint32_t items){
@@ -909,8 +919,8 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
     if(stack_levels < 1) stack_levels = 1;
     if(stack_levels > kStackDepth) stack_levels = kStackDepth;
     size_t lds = (size_t) stack_levels * kBlock * sizeof(uint32_t);
-    if(flags & 2) hipLaunchKernelGGL((k_trace<true>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, wc);
-    else hipLaunchKernelGGL((k_trace<false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, wc);
+    if(flags & 2) hipLaunchKernelGGL((k_trace<true>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, wc);
+    else hipLaunchKernelGGL((k_trace<false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, wc);
 }
 
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass){
