@@ -47,7 +47,7 @@ struct TimedLaunch { hipEvent_t a, b; int cls; };
 
 struct hpt_scene {
     SceneDev sd{};
-    BvhNode *d_nodes = nullptr; DevTriangle *d_tris = nullptr; DevRound *d_rounds = nullptr;
+    BvhNode *d_nodes = nullptr; QBvhNode *d_qnodes = nullptr; DevTriangle *d_tris = nullptr; DevRound *d_rounds = nullptr;
     DevMaterial *d_mats = nullptr; DevLight *d_lights = nullptr;
     int device = 0;
     int stack_levels = kStackDepth;       // traversal stack entries per lane
@@ -474,6 +474,7 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
     hipError_t e = hipGetDevice(&s->device);
     if(e == hipSuccess){ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount; }
     if(e == hipSuccess) e = upload(hs.nodes, &s->d_nodes);
+    if(e == hipSuccess) e = upload(hs.qnodes, &s->d_qnodes);
     if(e == hipSuccess) e = upload(hs.tris, &s->d_tris);
     if(e == hipSuccess) e = upload(hs.rounds, &s->d_rounds);
     if(e == hipSuccess) e = upload(hs.materials, &s->d_mats);
@@ -485,6 +486,8 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
     }
     auto t1 = std::chrono::steady_clock::now();
     s->sd.nodes = (const float4 *) s->d_nodes; s->sd.tris = (const float4 *) s->d_tris;
+    s->sd.qnodes = (const uint4 *) s->d_qnodes;
+    for(int a = 0; a < 3; ++a){ s->sd.qorigin[a] = hs.qorigin[a]; s->sd.qscale[a] = hs.qscale[a]; }
     s->sd.rounds = s->d_rounds; s->sd.mats = s->d_mats; s->sd.lights = s->d_lights;
     s->sd.num_rounds = ns + nl; s->sd.num_spheres = ns; s->sd.num_lights = nl; s->sd.num_tris = nt;
     s->sd.num_mats = (int) hs.materials.size(); s->sd.pad = 0;
@@ -508,7 +511,7 @@ void hpt_scene_destroy(hpt_scene *s){
     hipFree(s->accum); hipFree(s->counters); hipFree(s->d_wc);
     if(s->h_count) hipHostFree(s->h_count);
     hipFree(s->d_local_own); hipFree(s->d_image_own);
-    hipFree(s->d_nodes); hipFree(s->d_tris); hipFree(s->d_rounds); hipFree(s->d_mats); hipFree(s->d_lights);
+    hipFree(s->d_nodes); hipFree(s->d_qnodes); hipFree(s->d_tris); hipFree(s->d_rounds); hipFree(s->d_mats); hipFree(s->d_lights);
     free_bdpt(s);
     if(s->ev_start) hipEventDestroy(s->ev_start);
     if(s->ev_stop) hipEventDestroy(s->ev_stop);

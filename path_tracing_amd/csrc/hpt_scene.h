@@ -28,6 +28,14 @@ struct BvhNode {           // 64 B
     float rmax[3]; uint32_t pad1;
 };
 
+// Quantised twin of BvhNode, 32 B: child boxes as 16-bit grid coordinates of the scene box
+// (min rounded down, max rounded up, so the quantised box contains the float box); two dwordx4
+// fetches per node visit instead of four.  Traversal only needs conservative boxes.
+struct QBvhNode {
+    uint16_t lmin[3], lmax[3], rmin[3], rmax[3];
+    uint32_t left, right;
+};
+
 struct DevTriangle {       // 48 B
     float v0[3]; uint32_t ordinal;   // reference scan ordinal (num_spheres + num_lights + input index)
     float e1[3]; uint32_t material;  // index into the material table
@@ -58,11 +66,14 @@ struct DevLight {          // 112 B
 };
 
 static_assert(sizeof(BvhNode) == 64 && sizeof(DevTriangle) == 48 && sizeof(DevRound) == 32, "layout");
+static_assert(sizeof(QBvhNode) == 32, "layout");
 static_assert(sizeof(DevMaterial) == 32 && sizeof(DevLight) == 112, "layout");
 
 // Host-side flattened scene, ready to upload.
 struct HostScene {
     std::vector<BvhNode> nodes;        // nodes[0] is the root (always an inner node)
+    std::vector<QBvhNode> qnodes;      // same tree, quantised boxes
+    float qorigin[3] = {0, 0, 0}, qscale[3] = {1, 1, 1};   // grid: coordinate = qorigin + q * qscale
     std::vector<DevTriangle> tris;     // leaf order
     std::vector<DevRound> rounds;      // spheres, then light balls
     std::vector<DevMaterial> materials;

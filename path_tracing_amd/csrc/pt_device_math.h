@@ -300,5 +300,4 @@ HPT_DEV bool hit_triangle(f3 ro, f3 rd, f3 v0, f3 e1, f3 e2, float max_dist, flo
     if(th > kEps && th < max_dist){ t = th; return true; }
     return false;
 }
-
 } // namespace hpt

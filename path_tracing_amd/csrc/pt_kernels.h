@@ -8,6 +8,8 @@ namespace hpt {
 
 struct SceneDev {
     const float4 *nodes;        // BvhNode as 4 x float4
+    const uint4 *qnodes;        // QBvhNode as 2 x uint4 (k_trace)
+    float qorigin[3], qscale[3];
     const float4 *tris;         // DevTriangle as 3 x float4, leaf order
     const DevRound *rounds;     // spheres then light balls
     const DevMaterial *mats;

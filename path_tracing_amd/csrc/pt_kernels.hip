@@ -609,6 +609,7 @@ void k_untile(Tiling tl, const float *gathered, float *image){
 // Chunk size: 256 -> 47.3, 512 -> 45.5, 1024 -> 49.6, 2048 -> 59.3 (long chunks leave the tail of
 // a launch to a few workgroups); refill threshold 8 -> 51.0, 16 -> 49.6, 32 -> 48.6, 48 -> 48.0.
 constexpr int kTraceChunk = 512;      // rays per workgroup
+constexpr uint32_t kDoneCode = 0xFFFFFFFEu;   // leaf-flagged code a finished walk parks in cur
 constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
 constexpr int kNodeMin = 4;           // fewer lanes than this still walking nodes (while others hold leaves): do the leaves first
                                       // (A/B: off 42.1 ms, 2: 39.9, 4: 39.4, 8: 40.2, 16: 41.3, 32: 43.2)
@@ -675,7 +676,9 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                         float dy = fabsf(rd.y) > 1e-20f ? rd.y : copysignf(1e-20f, rd.y);
                         float dz = fabsf(rd.z) > 1e-20f ? rd.z : copysignf(1e-20f, rd.z);
                         ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
-                        ox = ro.x * ix; oy = ro.y * iy; oz = ro.z * iz;
+                        // quantised boxes: plane = qorigin + q * qscale, so t = q * (qscale * inv) + (qorigin - o) * inv
+                        ox = (sc.qorigin[0] - ro.x) * ix; oy = (sc.qorigin[1] - ro.y) * iy; oz = (sc.qorigin[2] - ro.z) * iz;
+                        ix *= sc.qscale[0]; iy *= sc.qscale[1]; iz *= sc.qscale[2];
                         cur = 0u; sp = 0;
                         active = true;
                     }
@@ -700,71 +703,68 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                 n_lane_steps += 1; n_boxes += 2;
                 if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_wave_steps += 64;   // one wave trip
             }
-            const float4 *n = sc.nodes + (size_t) cur * 4;
-            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-            float a0 = fmaf(n0.x, ix, -ox), a1 = fmaf(n1.x, ix, -ox);
-            float b0 = fmaf(n0.y, iy, -oy), b1 = fmaf(n1.y, iy, -oy);
-            float c0 = fmaf(n0.z, iz, -oz), c1 = fmaf(n1.z, iz, -oz);
+            const uint4 *n = sc.qnodes + (size_t) cur * 2;
+            uint4 w0 = n[0], w1 = n[1];
+            // lmin.xyz lmax.xyz rmin.xyz rmax.xyz as 16-bit grid coordinates, then the two child codes
+            float a0 = fmaf((float) (w0.x & 0xFFFFu), ix, ox), a1 = fmaf((float) (w0.y >> 16), ix, ox);
+            float b0 = fmaf((float) (w0.x >> 16), iy, oy), b1 = fmaf((float) (w0.z & 0xFFFFu), iy, oy);
+            float c0 = fmaf((float) (w0.y & 0xFFFFu), iz, oz), c1 = fmaf((float) (w0.z >> 16), iz, oz);
             float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
             float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
-            a0 = fmaf(n2.x, ix, -ox); a1 = fmaf(n3.x, ix, -ox);
-            b0 = fmaf(n2.y, iy, -oy); b1 = fmaf(n3.y, iy, -oy);
-            c0 = fmaf(n2.z, iz, -oz); c1 = fmaf(n3.z, iz, -oz);
+            a0 = fmaf((float) (w0.w & 0xFFFFu), ix, ox); a1 = fmaf((float) (w1.x >> 16), ix, ox);
+            b0 = fmaf((float) (w0.w >> 16), iy, oy); b1 = fmaf((float) (w1.y & 0xFFFFu), iy, oy);
+            c0 = fmaf((float) (w1.x & 0xFFFFu), iz, oz); c1 = fmaf((float) (w1.y >> 16), iz, oz);
             float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
             float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
-            uint32_t lc = f2u(n0.w), rc = f2u(n1.w);
+            uint32_t lc = w1.z, rc = w1.w;
             bool hl = (ln <= lf * 1.000002f) && (lc != kEmptyChild);
             bool hr = (rn <= rf * 1.000002f) && (rc != kEmptyChild);
-            if(hl && hr){
-                bool left_first = ln <= rn;
-                stk[sp * kBlock] = left_first ? rc : lc;
-                ++sp;
-                cur = left_first ? lc : rc;
-            } else if(hl) cur = lc;
-            else if(hr) cur = rc;
-            else if(sp > 0){ --sp; cur = stk[sp * kBlock]; }
-            else {
-                active = false;                                   // stack empty: ray finished
-                if(!ANY) pb.hit[path] = make_uint2(f2u(best_t), best_prim);
-                else {
-                    float4 c = sb.contrib[path];
-                    float4 col = pb.col[path];
-                    col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
-                    pb.col[path] = col;
-                }
-            }
+            // branch-free step (the exec-mask bookkeeping of nested ifs costs more scalar issue than
+            // the selects): always store the far child at the stack top, always fetch the entry below
+            // it, then pick by selects.  The stack has one spare level for the unconditional store.
+            bool any = hl || hr, both = hl && hr;
+            bool left_first = hl && (!hr || ln <= rn);
+            uint32_t top = stk[(sp > 0 ? sp - 1 : 0) * kBlock];
+            stk[sp * kBlock] = left_first ? rc : lc;
+            uint32_t near = left_first ? lc : rc;
+            cur = any ? near : (sp > 0 ? top : kDoneCode);
+            sp = any ? sp + (both ? 1 : 0) : (sp > 0 ? sp - 1 : 0);
         }
-        // phase 2: the leaf (lanes that left phase 1 early still hold an inner node and skip it)
+        // phase 2: the leaf (lanes that left phase 1 early still hold an inner node and skip it);
+        // kDoneCode = the walk found its stack empty
         if(active && (cur & kLeafFlag)){
-            if(COUNT){
-                n_leaf_lane += 1;
-                if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_leaf_wave += 64;
-            }
-            bool blocked = false;
-            uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
-            uint32_t cnt = (cur & 7u) + 1u;
-            for(uint32_t k = 0; k < cnt; ++k){
-                const float4 *tp = sc.tris + (size_t) (first + k) * 3;
-                float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                if(COUNT) n_tris += 1;
-                float t;
-                if(hit_triangle(ro, rd, xyz(t0), xyz(t1), xyz(t2), ANY ? tmax : 1e20f, t)){
-                    if(ANY){
-                        if(t > 1e-3f && (f2u(t2.w) & 1u)) blocked = true;
-                    } else {
-                        uint32_t ord = f2u(t0.w);
-                        if(t < best_t || (t == best_t && ord < best_ord)){
-                            best_t = t; best_prim = first + k; best_ord = ord; limit = t;
+            bool blocked = false, finished = cur == kDoneCode;
+            if(!finished){
+                if(COUNT){
+                    n_leaf_lane += 1;
+                    if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_leaf_wave += 64;
+                }
+                uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
+                uint32_t cnt = (cur & 7u) + 1u;
+                for(uint32_t k = 0; k < cnt; ++k){
+                    const float4 *tp = sc.tris + (size_t) (first + k) * 3;
+                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    if(COUNT) n_tris += 1;
+                    float t;
+                    if(hit_triangle(ro, rd, xyz(t0), xyz(t1), xyz(t2), ANY ? tmax : 1e20f, t)){
+                        if(ANY){
+                            if(t > 1e-3f && (f2u(t2.w) & 1u)) blocked = true;
+                        } else {
+                            uint32_t ord = f2u(t0.w);
+                            if(t < best_t || (t == best_t && ord < best_ord)){
+                                best_t = t; best_prim = first + k; best_ord = ord; limit = t;
+                            }
                         }
                     }
                 }
+                if(ANY && blocked) finished = true;                   // occluded: no contribution
+                else if(sp > 0){ --sp; cur = stk[sp * kBlock]; }
+                else finished = true;
             }
-            if(ANY && blocked) active = false;                    // occluded: no contribution
-            else if(sp > 0){ --sp; cur = stk[sp * kBlock]; }
-            else {
+            if(finished){
                 active = false;
                 if(!ANY) pb.hit[path] = make_uint2(f2u(best_t), best_prim);
-                else {
+                else if(!blocked){
                     float4 c = sb.contrib[path];
                     float4 col = pb.col[path];
                     col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
@@ -918,7 +918,7 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
     if(g == 0u) return;
     if(stack_levels < 1) stack_levels = 1;
     if(stack_levels > kStackDepth) stack_levels = kStackDepth;
-    size_t lds = (size_t) stack_levels * kBlock * sizeof(uint32_t);
+    size_t lds = (size_t) (stack_levels + 1) * kBlock * sizeof(uint32_t);     // + the spare level of the branch-free step
     if(flags & 2) hipLaunchKernelGGL((k_trace<true>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, wc);
     else hipLaunchKernelGGL((k_trace<false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, wc);
 }

@@ -278,6 +278,33 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
     }
     hs.nodes.swap(B.nodes);
     hs.bvh_depth = B.max_depth_seen;
+    {   // quantised twin: 16-bit grid over the union of the (padded) node boxes
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for(const BvhNode &n : hs.nodes){
+            for(int a = 0; a < 3; ++a){
+                if(n.left != kEmptyChild){ lo[a] = std::min(lo[a], n.lmin[a]); hi[a] = std::max(hi[a], n.lmax[a]); }
+                if(n.right != kEmptyChild){ lo[a] = std::min(lo[a], n.rmin[a]); hi[a] = std::max(hi[a], n.rmax[a]); }
+            }
+        }
+        for(int a = 0; a < 3; ++a){
+            if(!(lo[a] <= hi[a])){ lo[a] = 0.0f; hi[a] = 1.0f; }
+            hs.qorigin[a] = lo[a];
+            float ext = hi[a] - lo[a];
+            hs.qscale[a] = ext > 0.0f ? ext / 65535.0f : 1.0f;
+            hs.qscale[a] = std::nextafter(hs.qscale[a], INFINITY);          // never shorter than the box
+        }
+        auto qlo = [&](float v, int a){ double q = std::floor(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) - 1.0; return (uint16_t) std::min(65535.0, std::max(0.0, q)); };
+        auto qhi = [&](float v, int a){ double q = std::ceil(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) + 1.0; return (uint16_t) std::min(65535.0, std::max(0.0, q)); };
+        hs.qnodes.resize(hs.nodes.size());
+        for(size_t i = 0; i < hs.nodes.size(); ++i){
+            const BvhNode &n = hs.nodes[i]; QBvhNode &q = hs.qnodes[i];
+            for(int a = 0; a < 3; ++a){
+                if(n.left != kEmptyChild){ q.lmin[a] = qlo(n.lmin[a], a); q.lmax[a] = qhi(n.lmax[a], a); } else { q.lmin[a] = 65535; q.lmax[a] = 0; }
+                if(n.right != kEmptyChild){ q.rmin[a] = qlo(n.rmin[a], a); q.rmax[a] = qhi(n.rmax[a], a); } else { q.rmin[a] = 65535; q.rmax[a] = 0; }
+            }
+            q.left = n.left; q.right = n.right;
+        }
+    }
     if(hs.bvh_depth > kMaxBvhDepth) return "internal error: BVH deeper than the traversal stack";
 
     hs.tris.resize(nt);
