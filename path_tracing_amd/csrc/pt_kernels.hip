@@ -608,7 +608,7 @@ void k_untile(Tiling tl, const float *gathered, float *image){
 //   same with one cursor per 128-B line (82 VGPRs) ................................... 47.5
 // Chunk size: 256 -> 47.3, 512 -> 45.5, 1024 -> 49.6, 2048 -> 59.3 (long chunks leave the tail of
 // a launch to a few workgroups); refill threshold 8 -> 51.0, 16 -> 49.6, 32 -> 48.6, 48 -> 48.0.
-constexpr int kTraceChunk = 512;      // rays per workgroup
+constexpr int kTraceChunk = 1024;     // rays per workgroup (with the branch-free node step: 512 -> 37.6 ms, 768 -> 36.5, 1024 -> 36.5, 1280 -> 36.1, 1536 -> 36.7, 2048 -> 38.4)
 constexpr uint32_t kDoneCode = 0xFFFFFFFEu;   // leaf-flagged code a finished walk parks in cur
 constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
 constexpr int kNodeMin = 4;           // fewer lanes than this still walking nodes (while others hold leaves): do the leaves first
