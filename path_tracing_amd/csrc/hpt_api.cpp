@@ -173,10 +173,13 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     int rc = make_tiling(W, H, &P, tl);
     if(rc) return rc;
 
-    // samples in flight per pass: fill about 4M path slots
+    // samples in flight per pass: about 64 Mi path slots (9 GiB of path state, queues and shadow
+    // records: nothing on a 288 GB device).  Fewer, larger passes amortise the low-occupancy tail
+    // iterations of every pass (config 3, ms per 256-spp render: 4 Mi slots 291, 8 Mi 243, 16 Mi 219,
+    // 64 Mi 196, 256 Mi 192).
     int spass = P.samples_per_pass;
     if(spass <= 0){
-        const long long target = 4ll << 20;
+        const long long target = 64ll << 20;
         spass = (int) std::max<long long>(1, target / tl.n_local);
     }
     spass = std::min(spass, spp);

@@ -18,7 +18,7 @@ res = {v: [] for v in variants}
 kern = {}
 for r in range(rounds + 1):
     for v in variants:
-        p = hpt.make_params(seed=1, flags=hpt.FLAG_TIME_KERNELS)
+        p = hpt.make_params(seed=1, flags=hpt.FLAG_TIME_KERNELS, samples_per_pass=int(os.environ.get("AB_SPASS", "0")))
         p.reserved = v
         img = scene.render_pt(cam, W, H, 4, spp, p)
         st = scene.stats()
