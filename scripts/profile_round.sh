@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/trace.log" 2>&1
 echo "trace exit $?"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 32 --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 64 --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1
   echo "pmc $C exit $?"
 done
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/pmc_TCC" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 32 --no-cpu-baseline > "$OUT/pmc_TCC.log" 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/pmc_TCC" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 64 --no-cpu-baseline > "$OUT/pmc_TCC.log" 2>&1
 echo "pmc TCC exit $?"

@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC"):
     for k in agg:
         for cn, v in agg[k].items(): out[k][cn] = v
         out[k]["dispatches"] = len(disp[k])
-res = {"tag": tag, "workload": "bench.py --steps 1 --warmup 0 --spp 32 (cfg3 scene, 1024x1024), one PMC counter set per run",
+res = {"tag": tag, "workload": "bench.py --steps 1 --warmup 0 --spp 64 (cfg3 scene, 1024x1024; one 64 Mi-slot pass = the launch sizes of the 256-spp bench), one PMC counter set per run",
        "note": "FETCH_SIZE/WRITE_SIZE are in KiB, summed over the kernel's dispatches; on gfx950 FETCH_SIZE tallies 128-B "
                "requests as 64 B (MI355X_MICROARCH.md, HBM section): read bytes = 2 x FETCH_SIZE x 1024; counts fabric-side "
                "requests including Infinity-Cache hits", "kernels": {}}
