@@ -68,6 +68,10 @@ typedef struct hpt_params {
 #define HPT_FLAG_COUNT_WORK 2    /* count BVH boxes/triangles tested (slower; fills hpt_stats) */
 #define HPT_FLAG_OUTPUT_SUM 4    /* leave the per-pixel sum over this call's samples, not the mean */
 #define HPT_FLAG_TIME_KERNELS 8  /* bracket every kernel launch with HIP events (fills hpt_stats.ms_*) */
+#define HPT_FLAG_RUSSIAN_ROULETTE 16 /* PT: unbiased roulette after every non-delta bounce, survival
+                                      * q = clamp(max throughput channel, 0.05, 1).  The reference has no
+                                      * roulette: off by default; it costs one extra uniform per
+                                      * bounce, so images differ from the roulette-free ones sample by sample */
 
 typedef struct hpt_stats {
     uint64_t samples;         /* camera samples traced by the last render */

@@ -19,7 +19,7 @@ class PtOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("rng_mode", C.c_int), ("trig_mode", C.c_int),
                 ("sample_offset", C.c_int), ("x0", C.c_int), ("y0", C.c_int), ("x1", C.c_int), ("y1", C.c_int),
                 ("threads", C.c_int), ("glass_shadow_opaque", C.c_int), ("max_delta", C.c_int),
-                ("output_sum", C.c_int), ("ball_draw_reversed", C.c_int)]
+                ("output_sum", C.c_int), ("russian_roulette", C.c_int), ("ball_draw_reversed", C.c_int)]
 
 
 class PtStats(C.Structure):
@@ -54,7 +54,7 @@ def _p(a):
 
 
 def pt_render(lights, spheres, tris, camera, W, H, max_depth, spp, *, seed=1, rng_mode=0, trig_mode=0,
-              sample_offset=0, window=None, threads=0, glass_shadow_opaque=0, max_delta=64, output_sum=False, ball_draw_reversed=False):
+              sample_offset=0, window=None, threads=0, glass_shadow_opaque=0, max_delta=64, output_sum=False, ball_draw_reversed=False, russian_roulette=False):
     """Unidirectional PT + NEE (restates src/pt_cu.cu:20-250).  Returns (image[H,W,3] f32, stats dict).
     Pixels outside `window` = (x0, y0, x1, y1) stay zero."""
     img = np.zeros((H, W, 3), np.float32)
@@ -63,6 +63,7 @@ def pt_render(lights, spheres, tris, camera, W, H, max_depth, spp, *, seed=1, rn
     o.x0, o.y0, o.x1, o.y1 = window if window else (0, 0, W, H)
     o.threads, o.glass_shadow_opaque, o.max_delta, o.output_sum = threads, glass_shadow_opaque, max_delta, int(output_sum)
     o.ball_draw_reversed = int(ball_draw_reversed)
+    o.russian_roulette = int(russian_roulette)
     st = PtStats()
     cam = np.ascontiguousarray(camera)
     lights = np.ascontiguousarray(lights)

@@ -36,6 +36,7 @@ struct OraclePtOpts {
     int glass_shadow_opaque;
     int max_delta;          // cap on free delta bounces per sample
     int output_sum;         // 1: write the per-pixel sum over samples instead of the mean
+    int russian_roulette;   // 1: unbiased roulette after every non-delta bounce (NOT in the reference; default off)
     int ball_draw_reversed; // 1: the three uniforms of a unit-ball try fill z,y,x (argument evaluation
                             //    order of make_float3(u(),u(),u()) is unspecified, geometric.cuh:410)
 };
@@ -267,6 +268,13 @@ V3 trace_sample(const Scene &sc, const RCamera &cam, int px, int py, int max_dep
         float cos_wi = fabsf(dot(hit.normal, wi));
         throughput = throughput * bsdf_val * cos_wi / pdf_omega;
         if(!is_valid_color(throughput)) break;
+        if(o.russian_roulette){
+            // survive with q = clamp(max throughput channel, 0.05, 1); survivors are scaled by 1/q
+            float q = fminf(1.0f, fmaxf(0.05f, fmaxf(throughput.x, fmaxf(throughput.y, throughput.z))));
+            float u = rng.next();
+            if(!(u < q)) break;
+            throughput = throughput / q;
+        }
         ray_d = wi;
         ray_o = hit.pos + hit.normal * kEps;
         last_is_delta = false;

@@ -26,6 +26,7 @@ FLAG_BRUTE_FORCE = 1
 FLAG_COUNT_WORK = 2
 FLAG_OUTPUT_SUM = 4
 FLAG_TIME_KERNELS = 8
+FLAG_RUSSIAN_ROULETTE = 16
 
 
 class HptError(RuntimeError):

@@ -4,6 +4,7 @@
 // PNG through zlib instead of OpenCV.  Extra flags the reference lacks:
 //   --width/--height  override the scene's R line        --seed N   reproducible streams
 //   --max-depth N     eye depth (reference: EYE_DEPTH 4)  --obj FILE append an OBJ's faces (current material: 0.7 grey diffuse)
+//   --rr              optional unbiased Russian roulette (pt)
 // --mode pt and --mode bdpt are built (ppm is outside this library); bdpt renders the reference's CPU
 // estimator (run_cpu_bdpt) on the GPU.
 #include "scene_model.hpp"
@@ -38,6 +39,7 @@ int main(int argc, char **argv){
         else if(arg == "--seed" && i + 1 < argc) seed = std::stoll(argv[++i]);
         else if(arg == "--max-depth" && i + 1 < argc) max_depth = std::stoi(argv[++i]);
         else if(arg == "--obj" && i + 1 < argc) obj_file = argv[++i];
+        else if(arg == "--rr") hpt_host::g_run_params.flags |= HPT_FLAG_RUSSIAN_ROULETTE;
         else if(arg == "--help" || arg == "-h"){
             std::cout << "Usage: pt_cli [options]\n"
                       << "Options:\n"
@@ -50,7 +52,8 @@ int main(int argc, char **argv){
                       << "  --width/--height <int>  override the scene's R line\n"
                       << "  --seed <int>      reproducible random streams (default: clock)\n"
                       << "  --max-depth <int> eye depth (default: 4)\n"
-                      << "  --obj <file>      append the faces of a Wavefront OBJ\n";
+                      << "  --obj <file>      append the faces of a Wavefront OBJ\n"
+                      << "  --rr              unbiased Russian roulette (pt mode; not in the reference, off by default)\n";
             return 0;
         }
     }

@@ -242,7 +242,8 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
             }
             { LaunchTimer t(s, stream, timek, 1);
               launch_shade(stream, s->sd, s->pb, eq, &qcnt[it], slots, s->queue[cur ^ 1],
-                           &qcnt[it + 1], s->sb, s->squeue, &scnt[it], eye_depth, P.max_delta, wc); }
+                           &qcnt[it + 1], s->sb, s->squeue, &scnt[it], eye_depth, P.max_delta,
+                           (flags & HPT_FLAG_RUSSIAN_ROULETTE) ? 1 : 0, wc); }
             if(legacy){
                 LaunchTimer t(s, stream, timek, 2);
                 launch_connect(stream, s->sd, s->pb, s->sb, s->squeue, &scnt[it], slots, kflags, wc);

@@ -62,7 +62,7 @@ void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t
                    uint32_t max_items, int flags, WorkCounters *wc);
 void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
                   uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue,
-                  uint32_t *scount, int max_depth, int max_delta, WorkCounters *wc);
+                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc);
 void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,
                     const uint32_t *scount, uint32_t max_items, int flags, WorkCounters *wc);
 // merged closest-hit (equeue) + any-hit (squeue) launch; either queue may be absent (null count)

@@ -314,7 +314,7 @@ constexpr int kShadeTargetGroups = 1024; // workgroups a short queue is spread o
 __global__ __launch_bounds__(kBlock)
 void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
              uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue, uint32_t *scount,
-             int max_depth, int max_delta, WorkCounters *wc){
+             int max_depth, int max_delta, int roulette, WorkCounters *wc){
     __shared__ DevMaterial s_mats[kLdsMats];
     __shared__ DevLight s_lights[kLdsLights];
     // survivors and shadow requests of this workgroup's chunk are compacted in LDS (wave64
@@ -501,7 +501,14 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                             new_o = pos + normal * kEps;
                             last_is_delta = false;
                             ++depth;
-                            alive = is_valid_color(throughput) && depth < max_depth;
+                            alive = is_valid_color(throughput);
+                            if(alive && roulette){
+                                float q = fminf(1.0f, fmaxf(0.05f, fmaxf(throughput.x, fmaxf(throughput.y, throughput.z))));
+                                float u = rng_next(rs);
+                                alive = u < q;
+                                throughput = throughput / q;
+                            }
+                            alive = alive && depth < max_depth;
                         }
                         if(alive){
                             uint32_t nf = (last_is_delta ? 1u : 0u) | ((uint32_t) depth << 8) | ((uint32_t) delta_count << 16);
@@ -675,7 +682,9 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                         float dx = fabsf(rd.x) > 1e-20f ? rd.x : copysignf(1e-20f, rd.x);
                         float dy = fabsf(rd.y) > 1e-20f ? rd.y : copysignf(1e-20f, rd.y);
                         float dz = fabsf(rd.z) > 1e-20f ? rd.z : copysignf(1e-20f, rd.z);
-                        ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+                        // box tests only have to be conservative: the 1-ulp hardware reciprocal is inside the
+                        // 2e-6 slack of the slab test (the triangle tests below use exact arithmetic)
+                        ix = __builtin_amdgcn_rcpf(dx); iy = __builtin_amdgcn_rcpf(dy); iz = __builtin_amdgcn_rcpf(dz);
                         // quantised boxes: plane = qorigin + q * qscale, so t = q * (qscale * inv) + (qorigin - o) * inv
                         ox = (sc.qorigin[0] - ro.x) * ix; oy = (sc.qorigin[1] - ro.y) * iy; oz = (sc.qorigin[2] - ro.z) * iz;
                         ix *= sc.qscale[0]; iy *= sc.qscale[1]; iz *= sc.qscale[2];
@@ -879,14 +888,14 @@ void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t
 
 void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
                   uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue,
-                  uint32_t *scount, int max_depth, int max_delta, WorkCounters *wc){
+                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc){
     // enough workgroups for either chunking regime (see k_shade)
     uint32_t g = (max_items + kShadeChunk - 1) / kShadeChunk;
     if(g < (uint32_t) kShadeTargetGroups) g = (uint32_t) kShadeTargetGroups;
     uint32_t small = (max_items + kBlock - 1) / kBlock;
     if(small < g) g = small < 1u ? 1u : small;
     hipLaunchKernelGGL(k_shade, dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
-                       next_count, sb, squeue, scount, max_depth, max_delta, wc);
+                       next_count, sb, squeue, scount, max_depth, max_delta, roulette, wc);
 }
 
 void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,

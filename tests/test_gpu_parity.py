@@ -342,3 +342,22 @@ def test_bdpt_no_lights_and_one_shot_wrapper(hpt, sio, oracle_mod):
     assert rc == 0
     ref, _ = oracle_mod.bdpt_render(L, sp, tr, oracle_mod.object_order(None, sp, tr), sc.eye, sc.look_at, sc.view_up, sc.fov, 24, 24, 4, 4, 2, 8, seed=6)
     assert_parity(img, ref)
+
+
+def test_russian_roulette_is_opt_in_and_matches_the_oracle(hpt, sio, oracle_mod, input_scene):
+    """Not in the reference: default off; when asked for, the GPU and the oracle play the same
+    roulette (survival q = clamp(max throughput, 0.05, 1), one extra uniform per non-delta bounce)."""
+    sc, (L, sp, tr) = input_scene
+    cam = sio.camera_for(sc, 64, 48)
+    plain, _ = oracle_mod.pt_render(L, sp, tr, cam, 64, 48, 8, 16, seed=12)
+    ref, st = oracle_mod.pt_render(L, sp, tr, cam, 64, 48, 8, 16, seed=12, russian_roulette=True)
+    with hpt.Scene(L, sp, tr) as scene:
+        img = scene.render_pt(cam, 64, 48, 8, 16, hpt.make_params(seed=12, flags=hpt.FLAG_RUSSIAN_ROULETTE | hpt.FLAG_COUNT_WORK))
+        rays = scene.stats()["closest_rays"]
+        off = scene.render_pt(cam, 64, 48, 8, 16, hpt.make_params(seed=12))
+    assert_parity(img, ref)
+    assert_parity(off, plain)
+    assert rays == st["closest_rays"]
+    _, st_plain = oracle_mod.pt_render(L, sp, tr, cam, 64, 48, 8, 16, seed=12)
+    assert st["closest_rays"] < 0.9 * st_plain["closest_rays"]            # roulette does cut work at depth 8
+    assert abs(img.mean() - plain.mean()) < 0.1 * plain.mean()           # and keeps the expectation (up to the 15-clamp)
