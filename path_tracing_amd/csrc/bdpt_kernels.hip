@@ -674,18 +674,42 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
     }
 }
 
-// total_L of one eye vertex: the table row summed in light-vertex order, then added to the sample
+// total_L of one eye vertex: the table row summed in light-vertex order (the CPU loop's order, so the
+// float sums match bit for bit), then added to the sample.  One lane owns one vertex and adds serially;
+// the rows are fetched through LDS in tiles of 64 vertices x 8 entries so that every global load reads
+// whole 128-B lines (8 lanes x 16 B per row) instead of one 16-B piece per row.
+constexpr int kRedEntries = 8;
 __global__ __launch_bounds__(kBlock)
 void k_bdpt_reduce(PathBuf pb, BdptPathBuf bp, int n_lv, const uint32_t *cqueue, const uint32_t *ccount){
+    __shared__ float4 s_tile[kBlock / 64][64][kRedEntries + 1];          // +1: rows 144 B apart, conflict-free ds_read_b128
     uint32_t count = *ccount;
-    for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock){
-        uint32_t path = cqueue[i];
-        const float4 *row = bp.contrib + (size_t) path * n_lv;
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t waves_total = gridDim.x * (kBlock / 64);
+    for(uint32_t base = (blockIdx.x * (kBlock / 64) + wave) * 64u; base < count; base += waves_total * 64u){
+        uint32_t mine = base + lane;
+        uint32_t my_path = mine < count ? cqueue[mine] : 0u;
         f3 total = mk3(0, 0, 0);
-        for(int j = 0; j < n_lv; ++j){ float4 c = row[j]; total = total + xyz(c); }
-        float4 col = pb.col[path];
-        col.x = col.x + total.x; col.y = col.y + total.y; col.z = col.z + total.z;
-        pb.col[path] = col;
+        for(int e0 = 0; e0 < n_lv; e0 += kRedEntries){
+            // 8 loads: lanes (v = it * 8 + lane / 8, e = lane % 8)
+#pragma unroll
+            for(int it = 0; it < 8; ++it){
+                uint32_t v = (uint32_t) it * 8u + (lane >> 3);
+                int e = e0 + (int) (lane & 7u);
+                uint32_t vp = (uint32_t) __shfl((int) my_path, (int) v, 64);
+                float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if(base + v < count && e < n_lv) val = bp.contrib[(size_t) vp * n_lv + e];
+                s_tile[wave][v][lane & 7u] = val;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int lim = n_lv - e0 < kRedEntries ? n_lv - e0 : kRedEntries;
+            for(int e = 0; e < lim; ++e){ float4 c = s_tile[wave][lane][e]; total = total + xyz(c); }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if(mine < count){
+            float4 col = pb.col[my_path];
+            col.x = col.x + total.x; col.y = col.y + total.y; col.z = col.z + total.z;
+            pb.col[my_path] = col;
+        }
     }
 }
 
