@@ -131,11 +131,12 @@ def main():
         step(0)
     fence()
     t0 = time.perf_counter()
-    ext_ms, ext_n, tot_ms = 0.0, 0, 0.0
+    ext_ms, ext_n, tot_ms, res_ms, res_n = 0.0, 0, 0.0, 0.0, 0
     for _ in range(args.steps):
         step(hpt.FLAG_TIME_KERNELS)        # HIP events around every launch, on the launch stream
         st = scene.stats()                 # waits for this rank's render
         ext_ms += st["ms_extend"] + st["ms_connect"]; ext_n += st["n_extend"] + st["n_connect"]; tot_ms += st["ms_total"]
+        res_ms += st["ms_resume"]; res_n += st["n_resume"]
         shade_ms, connect_ms, other_ms = st["ms_shade"], st["ms_connect"], st["ms_other"]
     fence()
     dt = time.perf_counter() - t0
@@ -152,20 +153,27 @@ def main():
     if rank == 0:
         samples = W * H * args.spp
         value = samples * args.steps / dt / 1e6
-        # dominant kernel: k_trace (closest-hit + any-hit BVH traversal, one merged launch per
-        # iteration).  Algorithmic bytes per launch: 32 B per child box slab-tested + 36 B per triangle
-        # tested + 44 B per closest-hit ray (queue index, origin, direction in; hit record out) + 36 B
-        # per shadow ray (queue index, origin|max, direction in) -- DESIGN.md "Kernels".
+        # dominant kernel: k_trace (closest-hit + any-hit BVH traversal).  One trace step per iteration =
+        # the first launch (every ray, `split_budget` node steps) + the resume launch (the rays that need
+        # more); "launch" below is that pair, its duration the sum of the two HIP-event brackets.
+        # Algorithmic bytes per step: 32 B per child box slab-tested + 36 B per triangle tested + 44 B per
+        # closest-hit ray (queue index, origin, direction in; hit record out) + 36 B per shadow ray (queue
+        # index, origin|max, direction in), counted on the plain single-launch traversal of the same rays
+        # (the restarts of the split are not algorithmic work) -- DESIGN.md "Kernels".
         ext_bytes = (32.0 * (wc["boxes_closest"] + wc["boxes_shadow"]) + 36.0 * (wc["tris_closest"] + wc["tris_shadow"])
                      + 44.0 * wc["closest_rays"] + 36.0 * wc["shadow_rays"])
-        avg_launch_ms = ext_ms / max(ext_n, 1)
+        avg_first_ms = ext_ms / max(ext_n, 1)
+        avg_resume_ms = res_ms / max(res_n, 1)
+        avg_launch_ms = (ext_ms + res_ms) / max(ext_n, 1)
         launches_per_render = ext_n / max(args.steps, 1)
         bytes_per_launch = ext_bytes / max(launches_per_render, 1)
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
+        traffic = None; valu = None
         if os.path.exists(args.pmc_file):
             try:
-                traffic = json.load(open(args.pmc_file)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(args.pmc_file))
+                traffic = pmc.get("hbm_bytes_per_launch")
+                valu = pmc.get("trace_valu_utilization")
             except Exception:
                 traffic = None
         all_rays = wc["closest_rays"] + wc["shadow_rays"]
@@ -181,19 +189,25 @@ def main():
                                    % (len(tris), W, H, args.spp, args.depth),
                        "parallelism": "image tiles 32x32 round-robin over %d rank(s), %s gather to rank 0" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "seed": 1},
-            "roofline": {"bound": "hbm", "kernel": "k_trace (closest-hit + any-hit BVH traversal)",
+            "roofline": {"bound": "hbm", "kernel": "k_trace (closest-hit + any-hit BVH traversal; one step = first launch k_trace<false,false> + resume launch k_trace<false,true>)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy_peak": achieved / HBM_ACHIEVABLE_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_render,
+                         "avg_launch_ms": avg_launch_ms, "avg_first_launch_ms": avg_first_ms, "avg_resume_launch_ms": avg_resume_ms,
+                         "launches_per_step": launches_per_render, "split_budget": st["split_budget"],
+                         "long_ray_fraction_last_pass": st["long_rays_last_pass"] / max(st["traced_rays_last_pass"], 1),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "rank 0's kernels; bytes = 32*boxes + 36*tris + 44*closest rays + 36*shadow rays of this rank"},
+                         "valu_utilization_pmc": valu,
+                         "note": "rank 0's kernels; bytes = 32*boxes + 36*tris + 44*closest rays + 36*shadow rays of this rank. "
+                                 "The BVH and triangles of this scene stay in L2 / Infinity Cache, so the algorithmic bytes are not "
+                                 "HBM traffic (`traffic` is what the fabric saw, PMC) and frac can exceed 1; the kernel's binding limit "
+                                 "is VALU issue (valu_utilization_pmc = SQ_INSTS_VALU x 4 cycles / SIMD cycles, from profiles/)"},
             "work": {"rays_per_sample": all_rays / max(wc["samples"], 1),
                      "boxes_per_ray": (wc["boxes_closest"] + wc["boxes_shadow"]) / max(all_rays, 1),
                      "tris_per_ray": (wc["tris_closest"] + wc["tris_shadow"]) / max(all_rays, 1),
                      "algorithmic_bytes_per_sample": per_sample,
                      "Mrays_per_s": all_rays * world / (dt / args.steps) / 1e6 if world == 1 else None,
                      "device_ms_per_step_rank0": tot_ms / args.steps,
-                     "kernel_ms_last_step_rank0": {"trace": st["ms_extend"] + st["ms_connect"], "shade": shade_ms, "other": other_ms},
+                     "kernel_ms_last_step_rank0": {"trace": st["ms_extend"] + st["ms_connect"] + st["ms_resume"], "shade": shade_ms, "other": other_ms},
                      "bvh_nodes": wc["bvh_nodes"], "bvh_depth": wc["bvh_depth"], "ms_bvh_build": wc["ms_bvh_build"]},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -91,6 +91,11 @@ typedef struct hpt_stats {
      * lanes, wave_steps = 64 x the longest lane's trips summed over the wave's rays */
     uint64_t lane_steps_closest, wave_steps_closest, lane_steps_shadow, wave_steps_shadow;   /* inner-node trips */
     uint64_t leaf_lane_closest, leaf_wave_closest, leaf_lane_shadow, leaf_wave_shadow;       /* leaf trips */
+    /* split trace step: the first launch gives every ray split_budget node steps, the second (resume)
+     * launch finishes the rays that needed more */
+    double ms_resume;                 /* resume launches; TIME_KERNELS only (ms_extend / ms_connect then hold the first launches) */
+    uint32_t n_resume, split_budget;  /* split_budget 0: single-launch trace steps */
+    uint64_t traced_rays_last_pass, long_rays_last_pass;   /* rays entering the trace steps of the last pass / set aside for resume */
 } hpt_stats;
 
 const char *hpt_last_error(void);

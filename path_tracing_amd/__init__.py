@@ -51,7 +51,9 @@ class Stats(C.Structure):
                 ("lane_steps_closest", C.c_uint64), ("wave_steps_closest", C.c_uint64),
                 ("lane_steps_shadow", C.c_uint64), ("wave_steps_shadow", C.c_uint64),
                 ("leaf_lane_closest", C.c_uint64), ("leaf_wave_closest", C.c_uint64),
-                ("leaf_lane_shadow", C.c_uint64), ("leaf_wave_shadow", C.c_uint64)]
+                ("leaf_lane_shadow", C.c_uint64), ("leaf_wave_shadow", C.c_uint64),
+                ("ms_resume", C.c_double), ("n_resume", C.c_uint32), ("split_budget", C.c_uint32),
+                ("traced_rays_last_pass", C.c_uint64), ("long_rays_last_pass", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

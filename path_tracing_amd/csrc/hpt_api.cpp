@@ -43,6 +43,8 @@ hipError_t upload(const std::vector<T> &v, T **dptr){
 
 struct TimedLaunch { hipEvent_t a, b; int cls; };
 
+static_assert(sizeof(hpt_stats) == 248 && sizeof(hpt_params) == 40, "ABI records: keep path_tracing_amd/__init__.py and tests/test_boundary.py in step");
+
 } // namespace
 
 struct hpt_scene {
@@ -51,6 +53,7 @@ struct hpt_scene {
     DevMaterial *d_mats = nullptr; DevLight *d_lights = nullptr;
     int device = 0;
     int stack_levels = kStackDepth;       // traversal stack entries per lane
+    int last_counter_stride = 0, last_budget = 0;   // layout of `counters` after the last PT render (0: not a PT render)
     int num_cus = 256;
 
     // workspace, grown on demand
@@ -58,6 +61,7 @@ struct hpt_scene {
     PathBuf pb{}; ShadowBuf sb{};
     uint32_t *queue[2] = { nullptr, nullptr };   // path queues (ping-pong)
     uint32_t *squeue = nullptr;                  // shadow queue (path slots)
+    uint32_t *lqueue[2] = { nullptr, nullptr };  // rays set aside by the first trace launch: closest-hit, shadow
     uint32_t *counters = nullptr; int n_counters = 0;
     float4 *accum = nullptr;
     WorkCounters *d_wc = nullptr;
@@ -90,6 +94,7 @@ void free_workspace(hpt_scene *s){
     hipFree(s->pb.rng); hipFree(s->pb.hit);
     hipFree(s->sb.org_max); hipFree(s->sb.dir); hipFree(s->sb.contrib);
     hipFree(s->queue[0]); hipFree(s->queue[1]); hipFree(s->squeue); s->squeue = nullptr;
+    hipFree(s->lqueue[0]); hipFree(s->lqueue[1]); s->lqueue[0] = s->lqueue[1] = nullptr;
     s->pb = PathBuf{}; s->sb = ShadowBuf{}; s->queue[0] = s->queue[1] = nullptr; s->cap_paths = 0;
 }
 
@@ -108,6 +113,8 @@ int ensure_workspace(hpt_scene *s, size_t paths, size_t n_local, int n_counters)
         HIP_TRY(hipMalloc((void **) &s->queue[0], paths * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **) &s->queue[1], paths * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **) &s->squeue, paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &s->lqueue[0], paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &s->lqueue[1], paths * sizeof(uint32_t)));
         s->cap_paths = paths;
     }
     if(n_local > s->cap_local){
@@ -186,7 +193,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     size_t paths = (size_t) tl.n_local * spass;
     if(paths > 0x7FFFFFF0ull) return fail(HPT_ERR_INVALID, "too many path slots per pass");
     int max_iters = eye_depth + P.max_delta + 1;
-    int n_counters = 2 * (max_iters + 2);
+    int n_counters = 4 * (max_iters + 2);
     rc = ensure_workspace(s, paths, tl.n_local, n_counters);
     if(rc) return rc;
 
@@ -215,11 +222,18 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         HIP_TRY(hipMemsetAsync(s->counters, 0, (size_t) n_counters * sizeof(uint32_t), stream));
         uint32_t *qcnt = s->counters;                 // qcnt[i]: paths entering iteration i
         uint32_t *scnt = s->counters + (max_iters + 2);   // scnt[i]: shadow rays of iteration i
+        uint32_t *lecnt = s->counters + 2 * (max_iters + 2);   // lecnt[i] / lscnt[i]: rays the trace launch of
+        uint32_t *lscnt = s->counters + 3 * (max_iters + 2);   // iteration i set aside for its second launch
         { LaunchTimer t(s, stream, timek, 3);
           launch_generate(stream, tl, cam, s->pb, &qcnt[0], sthis,
                           (uint32_t) (P.sample_offset + done), P.seed, wc); }
         int cur = 0;
         const bool legacy = brute || (P.reserved & 1);      // separate extend/connect kernels (the scan variants)
+        // node-step budget of the first trace launch (tuning bits 1..6: 0 = default, 0x3F = no split)
+        int budget = (P.reserved >> 1) & 0x3F;
+        budget = budget == 0 ? kTraceBudget : (budget == 0x3F ? 0 : budget);
+        if(count || legacy) budget = 0;                     // work counts are those of the plain single-launch traversal
+        s->last_budget = budget;
         int pending_shadow = -1;                            // iteration whose shadow queue is not traced yet
         for(int it = 0; it < max_iters; ++it){
             if(it >= eye_depth && ((it - eye_depth) & 1) == 0){
@@ -235,9 +249,14 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                   launch_extend(stream, s->sd, s->pb, eq, &qcnt[it], slots, kflags, wc); }
             } else {
                 // extension rays of this iteration + shadow rays of the previous one, one launch
-                LaunchTimer t(s, stream, timek, 0);
-                launch_trace(stream, s->sd, s->pb, s->sb, eq, &qcnt[it], slots, s->squeue,
-                             pending_shadow >= 0 ? &scnt[pending_shadow] : nullptr, slots, s->stack_levels, kflags, P.reserved, wc);
+                TraceSplit split{ s->lqueue[0], &lecnt[it], s->lqueue[1], &lscnt[it], budget };
+                { LaunchTimer t(s, stream, timek, 0);
+                  launch_trace(stream, s->sd, s->pb, s->sb, eq, &qcnt[it], slots, s->squeue,
+                               pending_shadow >= 0 ? &scnt[pending_shadow] : nullptr, slots, s->stack_levels, kflags, P.reserved, wc, &split); }
+                if(split.budget > 0){
+                    LaunchTimer t(s, stream, timek, 4);
+                    launch_trace_resume(stream, s->sd, s->pb, s->sb, true, pending_shadow >= 0, slots, s->stack_levels, wc, split);
+                }
                 pending_shadow = -1;
             }
             { LaunchTimer t(s, stream, timek, 1);
@@ -251,9 +270,14 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
             cur ^= 1;
         }
         if(pending_shadow >= 0){
-            LaunchTimer t(s, stream, timek, 2);
-            launch_trace(stream, s->sd, s->pb, s->sb, nullptr, nullptr, 0, s->squeue, &scnt[pending_shadow], slots,
-                         s->stack_levels, kflags, P.reserved, wc);
+            TraceSplit split{ s->lqueue[0], &lecnt[max_iters], s->lqueue[1], &lscnt[max_iters], budget };
+            { LaunchTimer t(s, stream, timek, 2);
+              launch_trace(stream, s->sd, s->pb, s->sb, nullptr, nullptr, 0, s->squeue, &scnt[pending_shadow], slots,
+                           s->stack_levels, kflags, P.reserved, wc, &split); }
+            if(split.budget > 0){
+                LaunchTimer t(s, stream, timek, 4);
+                launch_trace_resume(stream, s->sd, s->pb, s->sb, false, true, slots, s->stack_levels, wc, split);
+            }
         }
         { LaunchTimer t(s, stream, timek, 3);
           launch_resolve(stream, tl, s->pb, s->accum, sthis); }
@@ -265,6 +289,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     HIP_TRY(hipGetLastError());
     s->ev_valid = true;
     s->stats_pending = true;
+    s->last_counter_stride = max_iters + 2;
     return HPT_OK;
 }
 
@@ -274,13 +299,24 @@ int collect_stats(hpt_scene *s){
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
     s->stats.ms_total = ms;
-    double sum[4] = { 0, 0, 0, 0 }; uint32_t cnt[4] = { 0, 0, 0, 0 };
+    double sum[5] = { 0, 0, 0, 0, 0 }; uint32_t cnt[5] = { 0, 0, 0, 0, 0 };
     for(const TimedLaunch &t : s->timed){
         float e = 0.f;
         if(hipEventElapsedTime(&e, t.a, t.b) == hipSuccess){ sum[t.cls] += e; cnt[t.cls]++; }
     }
     s->stats.ms_extend = sum[0]; s->stats.ms_shade = sum[1]; s->stats.ms_connect = sum[2]; s->stats.ms_other = sum[3];
     s->stats.n_extend = cnt[0]; s->stats.n_shade = cnt[1]; s->stats.n_connect = cnt[2]; s->stats.n_other = cnt[3];
+    s->stats.ms_resume = sum[4]; s->stats.n_resume = cnt[4];
+    s->stats.split_budget = (uint32_t) s->last_budget;
+    s->stats.traced_rays_last_pass = s->stats.long_rays_last_pass = 0;
+    if(s->last_counter_stride > 0 && s->counters && 4 * s->last_counter_stride <= s->n_counters){
+        std::vector<uint32_t> h((size_t) 4 * s->last_counter_stride);
+        HIP_TRY(hipMemcpy(h.data(), s->counters, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for(int i = 0; i < s->last_counter_stride; ++i){
+            s->stats.traced_rays_last_pass += (uint64_t) h[i] + h[(size_t) s->last_counter_stride + i];
+            s->stats.long_rays_last_pass += (uint64_t) h[(size_t) 2 * s->last_counter_stride + i] + h[(size_t) 3 * s->last_counter_stride + i];
+        }
+    }
     WorkCounters wc;
     HIP_TRY(hipMemcpy(&wc, s->d_wc, sizeof wc, hipMemcpyDeviceToHost));
     s->stats.samples = wc.samples; s->stats.closest_rays = wc.closest_rays; s->stats.shadow_rays = wc.shadow_rays;
@@ -359,6 +395,7 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
     if(rc) return rc;
     rc = ensure_bdpt_scene(s);
     if(rc) return rc;
+    s->last_counter_stride = 0; s->last_budget = 0;
 
     const int total_light_paths = s->nl * spl;
     const int n_lv = total_light_paths * light_depth;

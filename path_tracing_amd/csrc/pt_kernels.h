@@ -54,6 +54,7 @@ constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
 constexpr uint32_t kHitRoundFlag = 0x80000000u;   // | index into rounds; else triangle slot
 
 constexpr int kBlock = 256;
+constexpr int kTraceBudget = 6;      // node steps a ray gets in the first trace launch before it is set aside
 
 void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb,
                      uint32_t *qcount, int samples_this_pass, uint32_t first_sample, uint64_t seed,
@@ -66,9 +67,15 @@ void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t 
 void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,
                     const uint32_t *scount, uint32_t max_items, int flags, WorkCounters *wc);
 // merged closest-hit (equeue) + any-hit (squeue) launch; either queue may be absent (null count)
+// split != null && split->budget > 0: rays needing more than `budget` node steps are set aside into the
+// long queues (their counters must be zero on entry) and finished by a second launch
+struct TraceSplit { uint32_t *equeue, *ecount, *squeue, *scount; int budget; };
 void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue,
                   const uint32_t *ecount, uint32_t max_extend, const uint32_t *squeue, const uint32_t *scount,
-                  uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc);
+                  uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc,
+                  const TraceSplit *split = nullptr);
+void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
+                         uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split);
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass);
 void launch_finalize(hipStream_t s, const Tiling &tl, const float4 *accum, float *d_local, float scale);
 void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, float *d_image);

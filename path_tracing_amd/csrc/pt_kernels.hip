@@ -620,13 +620,17 @@ constexpr uint32_t kDoneCode = 0xFFFFFFFEu;   // leaf-flagged code a finished wa
 constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
 constexpr int kNodeMin = 4;           // fewer lanes than this still walking nodes (while others hold leaves): do the leaves first
                                       // (A/B: off 42.1 ms, 2: 39.9, 4: 39.4, 8: 40.2, 16: 41.3, 32: 43.2)
+constexpr uint32_t kLongChunk = 2048; // the same three for the second launch of a split trace step (long rays only)
+constexpr int kLongRefillMin = 16;
+constexpr int kLongNodeMin = 8;
 constexpr uint32_t kTraceShortQueue = 1u << 20;   // below this many rays a workgroup takes 256 instead of kTraceChunk
 
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool RESUME>
 HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *queue,
-                         uint32_t end, uint32_t *stk, uint32_t *s_next, int refill_min, int node_min, WorkCounters *wc){
+                         uint32_t end, uint32_t *stk, uint32_t *s_next, int refill_min, int node_min, WorkCounters *wc,
+                         uint32_t budget, uint32_t *s_long, uint32_t *s_nlong){
     bool active = false, exhausted = false;
-    uint32_t path = 0u, cur = 0u;
+    uint32_t path = 0u, cur = 0u, steps = 0u;
     int sp = 0;
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
     float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
@@ -634,7 +638,27 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
     uint32_t best_prim = kHitMiss, best_ord = 0xFFFFFFFFu;
     unsigned long long n_lane_steps = 0, n_wave_steps = 0, n_boxes = 0, n_tris = 0, n_rays = 0, n_leaf_lane = 0, n_leaf_wave = 0;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t step_limit = budget != 0u ? budget : 0xFFFFFFFFu;
     for(;;){
+        if(!RESUME && budget != 0u){
+            // a ray that has used its node-step budget is set aside for the second launch (it restarts
+            // there with what it found so far as its limit), so this lane goes back to the short rays
+            bool defer = active && steps >= budget;
+            unsigned long long dm = __ballot(defer);
+            if(dm != 0ull){
+                uint32_t dn = (uint32_t) __popcll(dm);
+                uint32_t dprefix = __builtin_amdgcn_mbcnt_hi((uint32_t) (dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) dm, 0u));
+                int dleader = __ffsll((long long) dm) - 1;
+                uint32_t dbase = 0u;
+                if((int) lane == dleader) dbase = atomicAdd(s_nlong, dn);
+                dbase = (uint32_t) __shfl((int) dbase, dleader, 64);
+                if(defer){
+                    s_long[dbase + dprefix] = path;
+                    if(!ANY) pb.hit[path] = make_uint2(f2u(best_t), best_prim);
+                    active = false;
+                }
+            }
+        }
         unsigned long long idle = __ballot(!active);
         if(idle != 0ull && !exhausted && (idle == ~0ull || __popcll(idle) >= refill_min)){
             // ---- refill: idle lanes pull the next rays of this workgroup's chunk ----
@@ -653,9 +677,10 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                     if(ANY){
                         float4 a = sb.org_max[path], b = sb.dir[path];
                         ro = xyz(a); rd = xyz(b); tmax = a.w;
-                        if(COUNT) n_rays += 1;
-                        // spheres first (the reference scans them after the triangles; the result is a boolean)
-                        for(int r = 0; r < sc.num_spheres; ++r){
+                        if(COUNT && !RESUME) n_rays += 1;
+                        // spheres first (the reference scans them after the triangles; the result is a boolean);
+                        // a resumed ray has passed them already
+                        for(int r = 0; r < (RESUME ? 0 : sc.num_spheres); ++r){
                             DevRound rr = sc.rounds[r];
                             float t;
                             if(hit_sphere(ro, rd, mk3(rr.c[0], rr.c[1], rr.c[2]), rr.r, tmax, t) && t > 1e-3f && (rr.flags & 1u)) start = false;
@@ -665,7 +690,14 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                         float4 o = pb.org_eta[path], d = pb.dir_flags[path];
                         ro = xyz(o); rd = xyz(d);
                         if(f2u(d.w) & 2u) start = false;                    // slot outside the image
-                        else {
+                        else if(RESUME){
+                            // restart with the closest hit of the first launch as the limit
+                            uint2 h = pb.hit[path];
+                            best_t = u2f(h.x); best_prim = h.y; best_ord = 0xFFFFFFFFu;
+                            if(best_prim != kHitMiss)
+                                best_ord = (best_prim & kHitRoundFlag) ? (best_prim & ~kHitRoundFlag) : f2u(sc.tris[(size_t) best_prim * 3].w);
+                            limit = best_t;
+                        } else {
                             if(COUNT) n_rays += 1;
                             best_t = 1e20f; best_prim = kHitMiss; best_ord = 0xFFFFFFFFu;
                             for(int r = 0; r < sc.num_rounds; ++r){
@@ -688,7 +720,7 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                         // quantised boxes: plane = qorigin + q * qscale, so t = q * (qscale * inv) + (qorigin - o) * inv
                         ox = (sc.qorigin[0] - ro.x) * ix; oy = (sc.qorigin[1] - ro.y) * iy; oz = (sc.qorigin[2] - ro.z) * iz;
                         ix *= sc.qscale[0]; iy *= sc.qscale[1]; iz *= sc.qscale[2];
-                        cur = 0u; sp = 0;
+                        cur = 0u; sp = 0; steps = 0u;
                         active = true;
                     }
                 }
@@ -703,7 +735,7 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
         const unsigned long long idle_at_entry = __ballot(!active);
         // phase 1: walk inner nodes until this lane holds a leaf (or its ray is finished); when only a
         // few lanes are still descending while others wait with a leaf, go and do the leaves first
-        while(active && !(cur & kLeafFlag)){
+        while(active && !(cur & kLeafFlag) && (RESUME || steps < step_limit)){
             if(node_min > 0){
                 unsigned long long walking = __ballot(true);
                 if(__popcll(walking) < node_min && __popcll(walking) < 64 - (int) __popcll(idle_at_entry)) break;
@@ -712,6 +744,7 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                 n_lane_steps += 1; n_boxes += 2;
                 if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_wave_steps += 64;   // one wave trip
             }
+            if(!RESUME) steps += 1u;
             const uint4 *n = sc.qnodes + (size_t) cur * 2;
             uint4 w0 = n[0], w1 = n[1];
             // lmin.xyz lmax.xyz rmin.xyz rmax.xyz as 16-bit grid coordinates, then the two child codes
@@ -801,29 +834,52 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
     }
 }
 
-template <bool COUNT>
+// Two-launch split of one trace step (budget != 0): the first launch gives every ray `budget` node
+// steps; rays that need more (the few that run deep into a dense mesh) are set aside -- their slots
+// collected in LDS and appended to the long queue with one global atomic per workgroup -- and a second
+// launch (RESUME) restarts them with the partial result as the limit.  Lanes of the first launch are
+// therefore never parked on a long ray while the short rays around them wait for a refill; the result
+// is the same (closest hit with the ordinal tie-break, or the occlusion boolean, of the same ray).
+struct LongQueues { uint32_t *equeue, *ecount, *squeue, *scount; uint32_t budget; };
+
+template <bool COUNT, bool RESUME>
 __global__ __launch_bounds__(kBlock)
 void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, const uint32_t *ecount_ptr,
-             const uint32_t *squeue, const uint32_t *scount_ptr, uint32_t chunk_rays, int refill_min, int node_min, WorkCounters *wc){
-    extern __shared__ uint32_t s_dyn_stack[];        // [stack level][lane], sized by the BVH depth
-    __shared__ uint32_t s_next;
+             const uint32_t *squeue, const uint32_t *scount_ptr, uint32_t chunk_rays, int refill_min, int node_min,
+             int stack_words, LongQueues lq, WorkCounters *wc){
+    extern __shared__ uint32_t s_dyn_stack[];        // [stack level][lane], sized by the BVH depth; then the long-ray list
+    __shared__ uint32_t s_next, s_nlong, s_gbase;
+    uint32_t *s_long = s_dyn_stack + stack_words;
     uint32_t ecount = ecount_ptr ? *ecount_ptr : 0u, scount = scount_ptr ? *scount_ptr : 0u;
     // short queues (the delta-bounce tail) get one ray per lane so they spread over every CU
     uint32_t ce = ecount >= kTraceShortQueue ? chunk_rays : (uint32_t) kBlock;
     uint32_t cs = scount >= kTraceShortQueue ? chunk_rays : (uint32_t) kBlock;
     uint32_t ne = (ecount + ce - 1) / ce, ns = (scount + cs - 1) / cs;
-    uint32_t bid = blockIdx.x;
-    if(bid >= ne + ns) return;
-    bool shadow = bid >= ne;
-    uint32_t chunk = shadow ? bid - ne : bid;
-    uint32_t csize = shadow ? cs : ce;
-    uint32_t begin = chunk * csize;
-    uint32_t total = shadow ? scount : ecount;
-    uint32_t end = begin + csize < total ? begin + csize : total;
-    if(threadIdx.x == 0) s_next = begin;
-    __syncthreads();
-    if(shadow) trace_chunk<true, COUNT>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc);
-    else trace_chunk<false, COUNT>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc);
+    for(uint32_t bid = blockIdx.x; bid < ne + ns; bid += gridDim.x){
+        bool shadow = bid >= ne;
+        uint32_t chunk = shadow ? bid - ne : bid;
+        uint32_t csize = shadow ? cs : ce;
+        uint32_t begin = chunk * csize;
+        uint32_t total = shadow ? scount : ecount;
+        uint32_t end = begin + csize < total ? begin + csize : total;
+        if(threadIdx.x == 0){ s_next = begin; s_nlong = 0u; }
+        __syncthreads();
+        if(shadow) trace_chunk<true, COUNT, RESUME>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
+                                                    lq.budget, s_long, &s_nlong);
+        else trace_chunk<false, COUNT, RESUME>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
+                                               lq.budget, s_long, &s_nlong);
+        __syncthreads();
+        if(!RESUME && lq.budget != 0u){
+            uint32_t n = s_nlong;
+            if(n != 0u){
+                if(threadIdx.x == 0) s_gbase = atomicAdd(shadow ? lq.scount : lq.ecount, n);
+                __syncthreads();
+                uint32_t *dst = (shadow ? lq.squeue : lq.equeue) + s_gbase;
+                for(uint32_t i = threadIdx.x; i < n; i += kBlock) dst[i] = s_long[i];
+            }
+        }
+        __syncthreads();
+    }
 }
 
 template <bool BRUTE>
@@ -910,7 +966,7 @@ void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb,
 
 void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue,
                   const uint32_t *ecount, uint32_t max_extend, const uint32_t *squeue, const uint32_t *scount,
-                  uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc){
+                  uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc, const TraceSplit *split){
     uint32_t chunk = ((tuning >> 16) & 0xFF) ? (uint32_t) ((tuning >> 16) & 0xFF) * 256u : (uint32_t) kTraceChunk;
     int refill_min = ((tuning >> 8) & 0xFF) ? ((tuning >> 8) & 0xFF) : kRefillMin;
     int node_min = ((tuning >> 24) & 0x7F) ? ((tuning >> 24) & 0x7F) : kNodeMin;
@@ -927,9 +983,42 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
     if(g == 0u) return;
     if(stack_levels < 1) stack_levels = 1;
     if(stack_levels > kStackDepth) stack_levels = kStackDepth;
-    size_t lds = (size_t) (stack_levels + 1) * kBlock * sizeof(uint32_t);     // + the spare level of the branch-free step
-    if(flags & 2) hipLaunchKernelGGL((k_trace<true>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, wc);
-    else hipLaunchKernelGGL((k_trace<false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, wc);
+    int stack_words = (stack_levels + 1) * kBlock;                            // + the spare level of the branch-free step
+    const bool count = (flags & 2) != 0;
+    LongQueues lq{};
+    if(split && split->budget > 0 && !count){
+        lq.equeue = split->equeue; lq.ecount = split->ecount; lq.squeue = split->squeue; lq.scount = split->scount;
+        lq.budget = (uint32_t) split->budget;
+    }
+    size_t lds = (size_t) stack_words * sizeof(uint32_t) + (lq.budget ? (size_t) chunk * sizeof(uint32_t) : 0);
+    if(count) hipLaunchKernelGGL((k_trace<true, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
+    else hipLaunchKernelGGL((k_trace<false, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
+}
+
+// second launch of a split trace step: the rays launch_trace set aside.  Their number is only known on
+// the device, so a fixed grid walks the chunks.
+void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
+                         uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split){
+    if(!extend && !shadow) return;
+    if(stack_levels < 1) stack_levels = 1;
+    if(stack_levels > kStackDepth) stack_levels = kStackDepth;
+    int stack_words = (stack_levels + 1) * kBlock;
+    // every ray of this launch is a long one: lanes refill sooner, a workgroup takes more rays (a lane
+    // gets ~8 rays, which evens out their lengths) and the leaf phase waits for fewer stragglers
+    uint32_t chunk2 = kLongChunk; int refill2 = kLongRefillMin, node_min2 = kLongNodeMin;
+    if(const char *e = getenv("HPT_TUNE_LONG")){           // development: chunk/256 << 16 | refill << 8 | node_min
+        long v = strtol(e, nullptr, 0);
+        if((v >> 16) & 0xFF) chunk2 = (uint32_t) ((v >> 16) & 0xFF) * 256u;
+        if((v >> 8) & 0xFF) refill2 = (int) ((v >> 8) & 0xFF);
+        if(v & 0xFF) node_min2 = (int) (v & 0xFF);
+    }
+    uint32_t per = (max_items + kBlock - 1) / kBlock;
+    uint64_t g = (uint64_t) per * ((extend ? 1u : 0u) + (shadow ? 1u : 0u));
+    uint32_t g2 = g < 8192u ? (uint32_t) (g < 1u ? 1u : g) : 8192u;
+    LongQueues none{};
+    hipLaunchKernelGGL((k_trace<false, true>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
+                       extend ? split.equeue : nullptr, extend ? split.ecount : nullptr, shadow ? split.squeue : nullptr,
+                       shadow ? split.scount : nullptr, chunk2, refill2, node_min2, stack_words, none, wc);
 }
 
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass){

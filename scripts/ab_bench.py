@@ -16,6 +16,7 @@ scene = hpt.Scene(L, sp, tr)
 ref = None
 res = {v: [] for v in variants}
 kern = {}
+extra = {}
 for r in range(rounds + 1):
     for v in variants:
         p = hpt.make_params(seed=1, flags=hpt.FLAG_TIME_KERNELS, samples_per_pass=int(os.environ.get("AB_SPASS", "0")))
@@ -25,11 +26,11 @@ for r in range(rounds + 1):
         if ref is None: ref = img
         assert np.array_equal(img, ref), "variant %d changes the image" % v
         if r > 0:
-            res[v].append(st["ms_total"]); kern[v] = (st["ms_extend"], st["ms_shade"], st["ms_connect"], st["ms_other"], st["n_extend"])
+            res[v].append(st["ms_total"]); kern[v] = (st["ms_extend"] + st["ms_resume"], st["ms_shade"], st["ms_connect"], st["ms_other"], st["n_extend"]); extra[v] = (st["ms_resume"], st["long_rays_last_pass"] / max(st["traced_rays_last_pass"], 1))
 for v in variants:
     a = np.array(res[v])
     print("variant %#x: median %.2f ms  min %.2f  -> %.1f Msamples/s | extend %.1f shade %.1f connect %.1f other %.1f (n_ext %d)" % (
-        v, np.median(a), a.min(), W * H * spp / np.median(a) / 1e3, *kern[v]), flush=True)
+        v, np.median(a), a.min(), W * H * spp / np.median(a) / 1e3, *kern[v]) + " resume %.1f ms, long rays %.3f" % extra[v], flush=True)
 p = hpt.make_params(seed=1, flags=hpt.FLAG_COUNT_WORK); p.reserved = variants[0]
 scene.render_pt(cam, W, H, 4, spp, p)
 st = scene.stats()

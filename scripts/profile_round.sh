@@ -15,3 +15,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/pmc_TCC" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 64 --no-cpu-baseline > "$OUT/pmc_TCC.log" 2>&1
 echo "pmc TCC exit $?"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_SQ" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 64 --no-cpu-baseline > "$OUT/pmc_SQ.log" 2>&1
+echo "pmc SQ exit $?"

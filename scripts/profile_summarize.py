@@ -6,11 +6,14 @@ os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join("profiles", "%s_kernel_stats.csv" % tag))
 def kname(n):
+    if "k_trace<false, false>" in n: return "k_trace_first"      # first launch of a trace step (every ray, budgeted)
+    if "k_trace<false, true>" in n: return "k_trace_resume"      # second launch (the rays set aside)
+    if "k_trace<true" in n: return "k_trace_count"               # the counting render's plain traversal
     for k in ("k_trace", "k_shade", "k_generate", "k_resolve", "k_finalize", "k_untile", "k_extend", "k_connect"):
         if k in n: return k
     return None
 out = collections.defaultdict(dict)
-for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC"):
+for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ"):
     fs = glob.glob(os.path.join(src, "pmc_" + c, "*", "*_counter_collection.csv"))
     if not fs: continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
@@ -32,9 +35,21 @@ for k, a in out.items():
     if "TCC_HIT_sum" in a: d["l2_hit_rate"] = a["TCC_HIT_sum"] / max(a["TCC_HIT_sum"] + a["TCC_MISS_sum"], 1); d["TCC_REQ_sum"] = a["TCC_REQ_sum"]
     if "read_bytes_corrected" in d and "write_bytes" in d and d["dispatches"]:
         d["hbm_bytes_per_launch"] = (d["read_bytes_corrected"] + d["write_bytes"]) / d["dispatches"]
+    if "SQ_INSTS_VALU" in a and a.get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction occupies its SIMD for 4 cycles,
+        # 256 CUs x 4 SIMDs: peak = 256 wave-instructions per cycle
+        cycles = a["GRBM_GUI_ACTIVE"] / 8.0
+        d["valu_wave_insts"] = a["SQ_INSTS_VALU"]; d["salu_insts"] = a.get("SQ_INSTS_SALU"); d["gpu_cycles"] = cycles
+        d["valu_utilization"] = a["SQ_INSTS_VALU"] / (cycles * 256.0)
+        if a.get("SQ_THREAD_CYCLES_VALU"): d["valu_active_lanes_avg"] = a["SQ_THREAD_CYCLES_VALU"] / a["SQ_INSTS_VALU"]
     res["kernels"][k] = d
-if "k_trace" in res["kernels"]:
-    res["hbm_bytes_per_launch"] = res["kernels"]["k_trace"].get("hbm_bytes_per_launch")
+kf, kr = res["kernels"].get("k_trace_first"), res["kernels"].get("k_trace_resume")
+if kf and kf.get("hbm_bytes_per_launch") is not None:
+    # one trace step = first launch + resume launch (same number of dispatches)
+    res["hbm_bytes_per_launch"] = kf["hbm_bytes_per_launch"] + ((kr or {}).get("hbm_bytes_per_launch") or 0.0)
+    res["hbm_bytes_per_launch_note"] = "k_trace_first + k_trace_resume, per trace step"
+if kf and kf.get("valu_utilization") is not None:
+    res["trace_valu_utilization"] = {"first": kf["valu_utilization"], "resume": (kr or {}).get("valu_utilization")}
 json.dump(res, open(os.path.join("profiles", "%s_pmc_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(res, indent=1))
 print(open(os.path.join("profiles", "%s_kernel_stats.csv" % tag)).read()[:1500])

@@ -361,3 +361,34 @@ def test_russian_roulette_is_opt_in_and_matches_the_oracle(hpt, sio, oracle_mod,
     _, st_plain = oracle_mod.pt_render(L, sp, tr, cam, 64, 48, 8, 16, seed=12)
     assert st["closest_rays"] < 0.9 * st_plain["closest_rays"]            # roulette does cut work at depth 8
     assert abs(img.mean() - plain.mean()) < 0.1 * plain.mean()           # and keeps the expectation (up to the 15-clamp)
+
+
+def test_split_trace_step_does_not_change_the_image(hpt, sio, oracle_mod):
+    """A trace step is two launches: every ray gets `budget` node steps, the rays that need more restart in
+    a resume launch with their partial hit as the limit.  Whatever the budget (1 = practically every ray
+    resumes, 63 = no split), the image is the oracle's, bit for bit; the default budget sets some rays aside
+    on a scene with a dense mesh and reports them in the stats."""
+    L, sp, tr = sio.cornell_with_sphere(3000)
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 96, 96)
+    ref, _ = oracle_mod.pt_render(L, sp, tr, cam, 96, 96, 4, 4, seed=3)
+    with hpt.Scene(L, sp, tr) as scene:
+        fractions = {}
+        for budget in (0, 1, 2, 3, 12, 63):
+            p = hpt.make_params(seed=3, flags=hpt.FLAG_TIME_KERNELS)
+            p.reserved = budget << 1
+            img = scene.render_pt(cam, 96, 96, 4, 4, p)
+            st = scene.stats()
+            assert_parity(img, ref)
+            fractions[budget] = st["long_rays_last_pass"] / max(st["traced_rays_last_pass"], 1)
+            assert st["split_budget"] == (hpt_default_budget() if budget == 0 else (0 if budget == 63 else budget))
+            assert (st["n_resume"] > 0) == (budget != 63)
+        assert fractions[63] == 0.0 and fractions[1] > 0.9
+        assert 0.0 < fractions[0] < 0.5 and fractions[12] < fractions[0] <= fractions[3] <= fractions[1]
+        # counting renders use the plain traversal, so the work counts do not depend on the split
+        p = hpt.make_params(seed=3, flags=hpt.FLAG_COUNT_WORK)
+        scene.render_pt(cam, 96, 96, 4, 4, p)
+        assert scene.stats()["split_budget"] == 0
+
+
+def hpt_default_budget():
+    return 6          # kTraceBudget, csrc/pt_kernels.h
