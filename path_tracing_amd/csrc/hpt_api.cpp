@@ -51,6 +51,7 @@ struct hpt_scene {
     SceneDev sd{};
     BvhNode *d_nodes = nullptr; QBvhNode *d_qnodes = nullptr; DevTriangle *d_tris = nullptr; DevRound *d_rounds = nullptr;
     DevMaterial *d_mats = nullptr; DevLight *d_lights = nullptr;
+    float4 *d_tri_frames = nullptr;
     int device = 0;
     int stack_levels = kStackDepth;       // traversal stack entries per lane
     int last_counter_stride = 0, last_budget = 0;   // layout of `counters` after the last PT render (0: not a PT render)
@@ -525,8 +526,19 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
         hpt_scene_destroy(s);
         return fail(HPT_ERR_DEVICE, msg);
     }
+    e = hipMalloc((void **) &s->d_tri_frames, std::max<size_t>((size_t) nt, 1) * 4 * sizeof(float4));
+    if(e == hipSuccess){
+        launch_tri_frames(nullptr, (const float4 *) s->d_tris, nt, s->d_tri_frames);
+        e = hipDeviceSynchronize();
+    }
+    if(e != hipSuccess){
+        std::string msg = std::string("triangle frames: ") + hipGetErrorString(e);
+        hpt_scene_destroy(s);
+        return fail(HPT_ERR_DEVICE, msg);
+    }
     auto t1 = std::chrono::steady_clock::now();
     s->sd.nodes = (const float4 *) s->d_nodes; s->sd.tris = (const float4 *) s->d_tris;
+    s->sd.tri_frames = s->d_tri_frames;
     s->sd.qnodes = (const uint4 *) s->d_qnodes;
     for(int a = 0; a < 3; ++a){ s->sd.qorigin[a] = hs.qorigin[a]; s->sd.qscale[a] = hs.qscale[a]; }
     s->sd.rounds = s->d_rounds; s->sd.mats = s->d_mats; s->sd.lights = s->d_lights;
@@ -553,6 +565,7 @@ void hpt_scene_destroy(hpt_scene *s){
     if(s->h_count) hipHostFree(s->h_count);
     hipFree(s->d_local_own); hipFree(s->d_image_own);
     hipFree(s->d_nodes); hipFree(s->d_qnodes); hipFree(s->d_tris); hipFree(s->d_rounds); hipFree(s->d_mats); hipFree(s->d_lights);
+    hipFree(s->d_tri_frames);
     free_bdpt(s);
     if(s->ev_start) hipEventDestroy(s->ev_start);
     if(s->ev_stop) hipEventDestroy(s->ev_stop);

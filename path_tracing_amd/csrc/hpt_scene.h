@@ -49,9 +49,10 @@ struct DevRound {          // 32 B: sphere or light ball
     uint32_t pad[2];
 };
 
-struct DevMaterial {       // 32 B
+struct DevMaterial {       // 48 B
     float base[3]; float roughness;
     float metallic; float eta; uint32_t type; uint32_t pad;
+    float diffuse[3]; float pad2;            // base / pi * (1 - metallic): the diffuse lobe of every BSDF value (geometric.cuh:433)
 };
 
 struct DevLight {          // 112 B
@@ -67,7 +68,7 @@ struct DevLight {          // 112 B
 
 static_assert(sizeof(BvhNode) == 64 && sizeof(DevTriangle) == 48 && sizeof(DevRound) == 32, "layout");
 static_assert(sizeof(QBvhNode) == 32, "layout");
-static_assert(sizeof(DevMaterial) == 32 && sizeof(DevLight) == 112, "layout");
+static_assert(sizeof(DevMaterial) == 48 && sizeof(DevLight) == 112, "layout");
 
 // Host-side flattened scene, ready to upload.
 struct HostScene {

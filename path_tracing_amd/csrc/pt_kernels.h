@@ -11,6 +11,7 @@ struct SceneDev {
     const uint4 *qnodes;        // QBvhNode as 2 x uint4 (k_trace)
     float qorigin[3], qscale[3];
     const float4 *tris;         // DevTriangle as 3 x float4, leaf order
+    const float4 *tri_frames;   // per triangle 4 x float4: shading normal and both local frames (launch_tri_frames)
     const DevRound *rounds;     // spheres then light balls
     const DevMaterial *mats;
     const DevLight *lights;
@@ -76,6 +77,8 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
                   const TraceSplit *split = nullptr);
 void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
                          uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split);
+// fills frames[4 * num_tris] from tris (once per scene)
+void launch_tri_frames(hipStream_t s, const float4 *tris, int num_tris, float4 *frames);
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass);
 void launch_finalize(hipStream_t s, const Tiling &tl, const float4 *accum, float *d_local, float scale);
 void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, float *d_image);

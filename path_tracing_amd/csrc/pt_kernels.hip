@@ -306,7 +306,7 @@ void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue, co
     if(COUNT) flush_tally(tally, rays, wc, true);
 }
 
-constexpr int kLdsMats = 256;    // material records staged in LDS (8 KiB)
+constexpr int kLdsMats = 256;    // material records staged in LDS (12 KiB)
 constexpr int kLdsLights = 64;   // light records staged in LDS (7 KiB)
 constexpr int kShadeChunk = 2048;        // paths per workgroup at most (LDS staging capacity)
 constexpr int kShadeTargetGroups = 1024; // workgroups a short queue is spread over
@@ -328,7 +328,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     const bool lights_in_lds = sc.num_lights <= kLdsLights;
     if(mats_in_lds){
         const uint32_t *src = (const uint32_t *) sc.mats; uint32_t *dst = (uint32_t *) s_mats;
-        for(int w = threadIdx.x; w < sc.num_mats * 8; w += kBlock) dst[w] = src[w];
+        for(int w = threadIdx.x; w < sc.num_mats * (int) (sizeof(DevMaterial) / 4); w += kBlock) dst[w] = src[w];
     }
     if(lights_in_lds){
         const uint32_t *src = (const uint32_t *) sc.lights; uint32_t *dst = (uint32_t *) s_lights;
@@ -369,18 +369,28 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                 f3 pos = ro + rd * t;
                 f3 wo = rd * -1.0f;
                 f3 normal; uint32_t mat_idx = 0; bool is_light = false; uint32_t light_idx = 0;
+                bool have_frame = false; f3 frame_T = mk3(0, 0, 0), frame_B = mk3(0, 0, 0);
                 if(prim & kHitRoundFlag){
                     DevRound r = sc.rounds[prim & 0x7FFFFFFFu];
                     normal = normalize3(pos - mk3(r.c[0], r.c[1], r.c[2]));
                     is_light = (r.flags & 2u) != 0u;
                     mat_idx = r.material; light_idx = r.material;
+                    if(dot3(normal, rd) > 0.0f) normal = normal * -1.0f;
                 } else {
-                    const float4 *tp = sc.tris + (size_t) prim * 3;
-                    float4 t1 = tp[1], t2 = tp[2];
-                    normal = normalize3(cross3(xyz(t1), xyz(t2)));
-                    mat_idx = f2u(t1.w);
+                    // the triangle's unit normal and the local frames of both orientations were computed once
+                    // per scene by k_tri_frames with these same expressions
+                    const float4 *fp = sc.tri_frames + (size_t) prim * 4;
+                    float4 q0 = fp[0], q1 = fp[1], q2 = fp[2], q3 = fp[3];
+                    normal = mk3(q0.x, q0.y, q0.z);
+                    mat_idx = f2u(q3.w);
+                    have_frame = true;
+                    if(dot3(normal, rd) > 0.0f){
+                        normal = normal * -1.0f;
+                        frame_T = mk3(q2.y, q2.z, q2.w); frame_B = mk3(q3.x, q3.y, q3.z);
+                    } else {
+                        frame_T = mk3(q0.w, q1.x, q1.y); frame_B = mk3(q1.z, q1.w, q2.x);
+                    }
                 }
-                if(dot3(normal, rd) > 0.0f) normal = normal * -1.0f;
 
                 if(is_light){                                          // pt_cu.cu:59-122
                     const DevLight &hl = lights[light_idx];
@@ -418,9 +428,16 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     DevMaterial dm = mats[mat_idx];
                     Mat m; m.base = mk3(dm.base[0], dm.base[1], dm.base[2]);
                     m.roughness = dm.roughness; m.metallic = dm.metallic; m.eta = dm.eta;
+                    const f3 diffuse_pre = mk3(dm.diffuse[0], dm.diffuse[1], dm.diffuse[2]);
+                    // a delta lobe does not count as a bounce; any other material's path ends at max_depth, so on
+                    // its last bounce the sampled direction would never be used (pt_cu.cu:37, 228-241)
+                    const bool delta_mat = (m.eta > 0.0f && m.roughness < 0.001f && m.metallic < 0.01f) || (m.metallic > 0.99f && m.roughness < 0.001f);
+                    const bool last_bounce = !delta_mat && depth + 1 >= max_depth;
                     uint2 r2 = pb.rng[path];
                     uint64_t rs = ((uint64_t) r2.y << 32) | (uint64_t) r2.x;
-                    const ShadeCtx ctx = make_shade_ctx(normal, wo);
+                    ShadeCtx ctx;
+                    if(have_frame){ ctx.N = normal; ctx.T = frame_T; ctx.B = frame_B; ctx.wo = to_local(wo, frame_T, frame_B, normal); }
+                    else ctx = make_shade_ctx(normal, wo);
 
                     // next-event estimation, pt_cu.cu:125-202
                     if(m.eta <= 0.0f && (m.metallic < 0.99f || m.roughness > 0.01f) && sc.num_lights > 0){
@@ -432,7 +449,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                             float cos_surface = fmaxf(0.0f, dot3(normal, light_dir));
                             if(cos_surface > 0.0f){
                                 f3 brdf; float pdf_unused;
-                                bsdf_eval_pdf(m, ctx, light_dir, brdf, pdf_unused);
+                                bsdf_eval_pdf(m, ctx, light_dir, brdf, pdf_unused, &diffuse_pre);
                                 f3 contrib = throughput * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface * (float) sc.num_lights;
                                 if(is_valid_color(contrib)){
                                     want_shadow = true;
@@ -465,7 +482,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                                     float pdf_light_area = 1.0f / (sc.num_lights * L.area);
                                     float pdf_light_dir = pdf_light_area * dist2 / fmaxf(cos_light, 1e-6f);
                                     f3 brdf; float pdf_bsdf;
-                                    bsdf_eval_pdf(m, ctx, wi_light, brdf, pdf_bsdf);
+                                    bsdf_eval_pdf(m, ctx, wi_light, brdf, pdf_bsdf, &diffuse_pre);
                                     float p_l = pdf_light_dir * pdf_light_dir;
                                     float p_b = pdf_bsdf * pdf_bsdf;
                                     float mis_w = p_l / fmaxf(p_l + p_b, 1e-8f);
@@ -482,9 +499,11 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     }
 
                     // BSDF sampling and path continuation, pt_cu.cu:204-241
-                    float u_rr = rng_next(rs), u1 = rng_next(rs), u2 = rng_next(rs);
-                    f3 wi, bsdf_val; float pdf_omega, new_eta; bool is_delta;
-                    bsdf_sample(m, ctx, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta);
+                    f3 wi = mk3(0, 0, 0), bsdf_val = mk3(0, 0, 0); float pdf_omega = 0.0f, new_eta = ray_eta; bool is_delta = false;
+                    if(!last_bounce){
+                        float u_rr = rng_next(rs), u1 = rng_next(rs), u2 = rng_next(rs);
+                        bsdf_sample(m, ctx, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta, &diffuse_pre);
+                    }
                     if(!(pdf_omega <= 0.0f)){          // pt_cu.cu:214 (and the TIR return, defined: terminate)
                         f3 new_o;
                         if(is_delta){
@@ -563,6 +582,26 @@ void k_resolve(Tiling tl, PathBuf pb, float4 *accum, int samples){
         sum = sum + c;                                      // pt_cu.cu:245
     }
     accum[p] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+}
+
+// Per triangle, once per scene: the unit normal of pt_cu.cu's hit record (normalize(cross(e1, e2)),
+// geometric.cuh:286) and the local shading frame of geometric.cuh:421-424 for both orientations of
+// that normal (the shading normal is flipped against the ray).  Computed here, on the device, with the
+// functions k_shade would otherwise run per hit, so the values are the same bit for bit.
+//   q0 = N.xyz T.x | q1 = T.yz B.xy | q2 = B.z T'.xyz | q3 = B'.xyz material   (T', B': frame of -N)
+__global__ __launch_bounds__(kBlock)
+void k_tri_frames(const float4 *tris, int num_tris, float4 *frames){
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if(i >= num_tris) return;
+    float4 t1 = tris[(size_t) i * 3 + 1], t2 = tris[(size_t) i * 3 + 2];
+    f3 n = normalize3(cross3(xyz(t1), xyz(t2)));
+    f3 T, B, T2, B2;
+    build_local_frame(n, T, B);
+    build_local_frame(n * -1.0f, T2, B2);
+    frames[(size_t) i * 4 + 0] = make_float4(n.x, n.y, n.z, T.x);
+    frames[(size_t) i * 4 + 1] = make_float4(T.y, T.z, B.x, B.y);
+    frames[(size_t) i * 4 + 2] = make_float4(B.z, T2.x, T2.y, T2.z);
+    frames[(size_t) i * 4 + 3] = make_float4(B2.x, B2.y, B2.z, t1.w);
 }
 
 // d_local[p] = accum[p] / spp (scale_is_div) -- pt_cu.cu:248
@@ -1019,6 +1058,11 @@ void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBu
     hipLaunchKernelGGL((k_trace<false, true>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
                        extend ? split.equeue : nullptr, extend ? split.ecount : nullptr, shadow ? split.squeue : nullptr,
                        shadow ? split.scount : nullptr, chunk2, refill2, node_min2, stack_words, none, wc);
+}
+
+void launch_tri_frames(hipStream_t s, const float4 *tris, int num_tris, float4 *frames){
+    if(num_tris <= 0) return;
+    hipLaunchKernelGGL(k_tri_frames, dim3((num_tris + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tris, num_tris, frames);
 }
 
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass){

@@ -173,6 +173,10 @@ uint32_t intern_material(const RefMat &m, std::map<MatKey, uint32_t> &table, std
     DevMaterial d;
     d.base[0] = m.base[0]; d.base[1] = m.base[1]; d.base[2] = m.base[2];
     d.roughness = m.roughness; d.metallic = m.metallic; d.eta = m.eta; d.type = (uint32_t) m.type; d.pad = 0;
+    // same float operations as the kernel's `m.base / kPi * (1.0f - m.metallic)` (IEEE divide, no contraction)
+    const float pi = 3.14159265358979323846f;
+    for(int a = 0; a < 3; ++a){ float q = m.base[a] / pi; d.diffuse[a] = q * (1.0f - m.metallic); }
+    d.pad2 = 0.0f;
     uint32_t idx = (uint32_t) out.size();
     out.push_back(d);
     table.emplace(k, idx);
