@@ -42,6 +42,7 @@ hipError_t upload(const std::vector<T> &v, T **dptr){
 }
 
 struct TimedLaunch { hipEvent_t a, b; int cls; };
+constexpr int kSplitHold = 15;
 
 static_assert(sizeof(hpt_stats) == 248 && sizeof(hpt_params) == 40, "ABI records: keep path_tracing_amd/__init__.py and tests/test_boundary.py in step");
 
@@ -55,6 +56,11 @@ struct hpt_scene {
     int device = 0;
     int stack_levels = kStackDepth;       // traversal stack entries per lane
     int last_counter_stride = 0, last_budget = 0;   // layout of `counters` after the last PT render (0: not a PT render)
+    // default budget only: the share of rays the last split render set aside is read back asynchronously; a
+    // scene whose rays are nearly all long (every ray restarts: the split only costs) renders the next
+    // kSplitHold frames without the split, then is probed again
+    uint32_t *h_split = nullptr; int h_split_words = 0; hipEvent_t ev_split = nullptr;
+    bool split_probe_pending = false; int split_probe_stride = 0, split_hold = 0;
     int num_cus = 256;
 
     // workspace, grown on demand
@@ -213,6 +219,22 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     s->stats.ms_total = s->stats.ms_extend = s->stats.ms_shade = s->stats.ms_connect = s->stats.ms_other = 0.0;
     s->stats.n_extend = s->stats.n_shade = s->stats.n_connect = s->stats.n_other = 0;
 
+    // split of the trace step: decided from the previous render of this scene (see hpt_scene::h_split)
+    const bool auto_budget = ((P.reserved >> 1) & 0x3F) == 0;
+    bool split_off = false;
+    if(auto_budget){
+        if(s->split_probe_pending && hipEventQuery(s->ev_split) == hipSuccess){
+            s->split_probe_pending = false;
+            uint64_t traced = 0, set_aside = 0;
+            for(int i = 0; i < s->split_probe_stride; ++i){
+                traced += (uint64_t) s->h_split[i] + s->h_split[(size_t) s->split_probe_stride + i];
+                set_aside += (uint64_t) s->h_split[(size_t) 2 * s->split_probe_stride + i] + s->h_split[(size_t) 3 * s->split_probe_stride + i];
+            }
+            if(traced > 0 && set_aside * 2 > traced) s->split_hold = kSplitHold;
+        }
+        if(s->split_hold > 0){ split_off = true; --s->split_hold; }
+    }
+
     HIP_TRY(hipMemsetAsync(s->d_wc, 0, sizeof(WorkCounters), stream));
     HIP_TRY(hipMemsetAsync(s->accum, 0, (size_t) tl.n_local * sizeof(float4), stream));
     HIP_TRY(hipEventRecord(s->ev_start, stream));
@@ -234,6 +256,13 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         int budget = (P.reserved >> 1) & 0x3F;
         budget = budget == 0 ? kTraceBudget : (budget == 0x3F ? 0 : budget);
         if(count || legacy) budget = 0;                     // work counts are those of the plain single-launch traversal
+        int tuning = P.reserved;
+        if(auto_budget && split_off){
+            budget = 0;                                     // all rays long: single launches with the long-ray tuning
+            if(((tuning >> 16) & 0xFF) == 0) tuning |= (int) (kLongChunk / 256u) << 16;
+            if(((tuning >> 8) & 0xFF) == 0) tuning |= kLongRefillMin << 8;
+            if(((tuning >> 24) & 0x7F) == 0) tuning |= kLongNodeMin << 24;
+        }
         s->last_budget = budget;
         int pending_shadow = -1;                            // iteration whose shadow queue is not traced yet
         for(int it = 0; it < max_iters; ++it){
@@ -253,7 +282,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                 TraceSplit split{ s->lqueue[0], &lecnt[it], s->lqueue[1], &lscnt[it], budget };
                 { LaunchTimer t(s, stream, timek, 0);
                   launch_trace(stream, s->sd, s->pb, s->sb, eq, &qcnt[it], slots, s->squeue,
-                               pending_shadow >= 0 ? &scnt[pending_shadow] : nullptr, slots, s->stack_levels, kflags, P.reserved, wc, &split); }
+                               pending_shadow >= 0 ? &scnt[pending_shadow] : nullptr, slots, s->stack_levels, kflags, tuning, wc, &split); }
                 if(split.budget > 0){
                     LaunchTimer t(s, stream, timek, 4);
                     launch_trace_resume(stream, s->sd, s->pb, s->sb, true, pending_shadow >= 0, slots, s->stack_levels, wc, split);
@@ -274,7 +303,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
             TraceSplit split{ s->lqueue[0], &lecnt[max_iters], s->lqueue[1], &lscnt[max_iters], budget };
             { LaunchTimer t(s, stream, timek, 2);
               launch_trace(stream, s->sd, s->pb, s->sb, nullptr, nullptr, 0, s->squeue, &scnt[pending_shadow], slots,
-                           s->stack_levels, kflags, P.reserved, wc, &split); }
+                           s->stack_levels, kflags, tuning, wc, &split); }
             if(split.budget > 0){
                 LaunchTimer t(s, stream, timek, 4);
                 launch_trace_resume(stream, s->sd, s->pb, s->sb, false, true, slots, s->stack_levels, wc, split);
@@ -287,6 +316,19 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     { LaunchTimer t(s, stream, timek, 3);
       launch_finalize(stream, tl, s->accum, d_local, divisor); }
     HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    if(auto_budget && s->last_budget > 0 && !s->split_probe_pending){
+        int words = 4 * (max_iters + 2);
+        if(words > s->h_split_words){
+            if(s->h_split) hipHostFree(s->h_split);
+            s->h_split = nullptr; s->h_split_words = 0;
+            HIP_TRY(hipHostMalloc((void **) &s->h_split, (size_t) words * sizeof(uint32_t)));
+            s->h_split_words = words;
+        }
+        if(!s->ev_split) HIP_TRY(hipEventCreateWithFlags(&s->ev_split, hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(s->h_split, s->counters, (size_t) words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(s->ev_split, stream));
+        s->split_probe_pending = true; s->split_probe_stride = max_iters + 2;
+    }
     HIP_TRY(hipGetLastError());
     s->ev_valid = true;
     s->stats_pending = true;
@@ -563,6 +605,8 @@ void hpt_scene_destroy(hpt_scene *s){
     free_workspace(s);
     hipFree(s->accum); hipFree(s->counters); hipFree(s->d_wc);
     if(s->h_count) hipHostFree(s->h_count);
+    if(s->h_split) hipHostFree(s->h_split);
+    if(s->ev_split) hipEventDestroy(s->ev_split);
     hipFree(s->d_local_own); hipFree(s->d_image_own);
     hipFree(s->d_nodes); hipFree(s->d_qnodes); hipFree(s->d_tris); hipFree(s->d_rounds); hipFree(s->d_mats); hipFree(s->d_lights);
     hipFree(s->d_tri_frames);

@@ -55,6 +55,11 @@ constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
 constexpr uint32_t kHitRoundFlag = 0x80000000u;   // | index into rounds; else triangle slot
 
 constexpr int kBlock = 256;
+// k_trace tuning for launches whose rays are all long (the resume launch of a split step; every launch of a
+// scene whose split is held off): rays per workgroup, idle lanes that trigger a refill, early-leaf-break threshold
+constexpr uint32_t kLongChunk = 2048;
+constexpr int kLongRefillMin = 16;
+constexpr int kLongNodeMin = 8;
 constexpr int kTraceBudget = 6;      // node steps a ray gets in the first trace launch before it is set aside
 
 void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb,

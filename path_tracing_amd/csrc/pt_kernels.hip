@@ -659,9 +659,6 @@ constexpr uint32_t kDoneCode = 0xFFFFFFFEu;   // leaf-flagged code a finished wa
 constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
 constexpr int kNodeMin = 4;           // fewer lanes than this still walking nodes (while others hold leaves): do the leaves first
                                       // (A/B: off 42.1 ms, 2: 39.9, 4: 39.4, 8: 40.2, 16: 41.3, 32: 43.2)
-constexpr uint32_t kLongChunk = 2048; // the same three for the second launch of a split trace step (long rays only)
-constexpr int kLongRefillMin = 16;
-constexpr int kLongNodeMin = 8;
 constexpr uint32_t kTraceShortQueue = 1u << 20;   // below this many rays a workgroup takes 256 instead of kTraceChunk
 
 template <bool ANY, bool COUNT, bool RESUME>

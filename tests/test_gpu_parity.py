@@ -392,3 +392,22 @@ def test_split_trace_step_does_not_change_the_image(hpt, sio, oracle_mod):
 
 def hpt_default_budget():
     return 6          # kTraceBudget, csrc/pt_kernels.h
+
+
+def test_split_is_dropped_for_scenes_whose_rays_are_all_long(hpt, sio, oracle_mod):
+    """With the default budget the renderer reads back (asynchronously) how many rays the split set aside;
+    when that is most of them the next frames of the scene use single-launch trace steps.  Same image."""
+    L, sp, tr = sio.cornell_random_triangles(4000)
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 64, 64)
+    ref, _ = oracle_mod.pt_render(L, sp, tr, cam, 64, 64, 4, 2, seed=5)
+    with hpt.Scene(L, sp, tr) as scene:
+        a = scene.render_pt(cam, 64, 64, 4, 2, hpt.make_params(seed=5))
+        st = scene.stats()
+        assert st["split_budget"] == hpt_default_budget()
+        assert st["long_rays_last_pass"] * 2 > st["traced_rays_last_pass"]
+        b = scene.render_pt(cam, 64, 64, 4, 2, hpt.make_params(seed=5))
+        assert scene.stats()["split_budget"] == 0
+        p = hpt.make_params(seed=5); p.reserved = 6 << 1               # an explicit budget is always honoured
+        c = scene.render_pt(cam, 64, 64, 4, 2, p)
+        assert scene.stats()["split_budget"] == 6
+    assert_parity(a, ref); assert_parity(b, ref); assert_parity(c, ref)
