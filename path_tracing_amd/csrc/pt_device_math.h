@@ -175,8 +175,12 @@ HPT_DEV ShadeCtx make_shade_ctx(f3 N, f3 wo_w){
 
 // BSDF value and pdf in one pass over the shared terms (the two reference functions,
 // geometric.cuh:419-456 and 458-484, build the same half vector, D and Lambda(wo)).
+// Terms of a BSDF query that depend on the hit only (material, outgoing direction), for callers that make
+// several queries at one hit: the diffuse lobe (a per-material constant) and Lambda(wo).
+struct ShadePre { f3 diffuse; float lam_o; };
+
 template <bool WANT_F = true, bool WANT_PDF = true>
-HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, float &pdf_out, const f3 *diffuse_pre = nullptr){
+HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, float &pdf_out, const ShadePre *pre = nullptr){
     f3 wo = c.wo;
     f3 wi = to_local(wi_w, c.T, c.B, c.N);
     f_out = mk3(0, 0, 0); pdf_out = 0.0f;
@@ -190,10 +194,10 @@ HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, 
     f3 wh = normalize3(whv);
     if(wh.z < 0.0f) wh = wh * -1.0f;
     float D = ggx_D(wh, alpha);
-    float lam_o = ggx_lambda(wo, alpha);
+    float lam_o = pre ? pre->lam_o : ggx_lambda(wo, alpha);
     float awo = fabsf(wo.z), awi = fabsf(wi.z);
     if(WANT_F && !eval_zero){
-        f3 diffuse = diffuse_pre ? *diffuse_pre : m.base / kPi * (1.0f - m.metallic);     // per-material constant, uploaded with the scene
+        f3 diffuse = pre ? pre->diffuse : m.base / kPi * (1.0f - m.metallic);
         if(wo.z * wi.z < 0.0f) diffuse = mk3(0, 0, 0);
         float G = 1.0f / (1.0f + lam_o + ggx_lambda(wi, alpha));
         f3 F;
@@ -216,7 +220,7 @@ HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, 
 // BSDF sampling (geometric.cuh:486-562).  pdf <= 0 means "terminate the path" for both the
 // non-delta rejection and the reference's uninitialised total-internal-reflection return.
 HPT_DEV void bsdf_sample(const Mat &m, const ShadeCtx &c, float u_rr, float u1, float u2, float cur_eta,
-                         f3 &wi_w, f3 &f, float &pdf, bool &is_delta, float &new_eta, const f3 *diffuse_pre = nullptr){
+                         f3 &wi_w, f3 &f, float &pdf, bool &is_delta, float &new_eta, const ShadePre *pre = nullptr){
     is_delta = false;
     new_eta = cur_eta;
     wi_w = mk3(0, 0, 0); f = mk3(0, 0, 0); pdf = 0.0f;
@@ -266,7 +270,7 @@ HPT_DEV void bsdf_sample(const Mat &m, const ShadeCtx &c, float u_rr, float u1, 
         if(wo.z < 0.0f) wi.z *= -1.0f;
     }
     wi_w = to_world(wi, c.T, c.B, c.N);
-    bsdf_eval_pdf(m, c, wi_w, f, pdf, diffuse_pre);
+    bsdf_eval_pdf(m, c, wi_w, f, pdf, pre);
 }
 
 // ---- primitive tests --------------------------------------------------------------------

@@ -428,7 +428,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     DevMaterial dm = mats[mat_idx];
                     Mat m; m.base = mk3(dm.base[0], dm.base[1], dm.base[2]);
                     m.roughness = dm.roughness; m.metallic = dm.metallic; m.eta = dm.eta;
-                    const f3 diffuse_pre = mk3(dm.diffuse[0], dm.diffuse[1], dm.diffuse[2]);
+                    ShadePre pre; pre.diffuse = mk3(dm.diffuse[0], dm.diffuse[1], dm.diffuse[2]);     // uploaded with the scene
                     // a delta lobe does not count as a bounce; any other material's path ends at max_depth, so on
                     // its last bounce the sampled direction would never be used (pt_cu.cu:37, 228-241)
                     const bool delta_mat = (m.eta > 0.0f && m.roughness < 0.001f && m.metallic < 0.01f) || (m.metallic > 0.99f && m.roughness < 0.001f);
@@ -438,6 +438,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     ShadeCtx ctx;
                     if(have_frame){ ctx.N = normal; ctx.T = frame_T; ctx.B = frame_B; ctx.wo = to_local(wo, frame_T, frame_B, normal); }
                     else ctx = make_shade_ctx(normal, wo);
+                    pre.lam_o = ggx_lambda(ctx.wo, roughness_to_alpha(m.roughness));     // shared by the NEE and the sampled query
 
                     // next-event estimation, pt_cu.cu:125-202
                     if(m.eta <= 0.0f && (m.metallic < 0.99f || m.roughness > 0.01f) && sc.num_lights > 0){
@@ -449,7 +450,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                             float cos_surface = fmaxf(0.0f, dot3(normal, light_dir));
                             if(cos_surface > 0.0f){
                                 f3 brdf; float pdf_unused;
-                                bsdf_eval_pdf(m, ctx, light_dir, brdf, pdf_unused, &diffuse_pre);
+                                bsdf_eval_pdf(m, ctx, light_dir, brdf, pdf_unused, &pre);
                                 f3 contrib = throughput * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface * (float) sc.num_lights;
                                 if(is_valid_color(contrib)){
                                     want_shadow = true;
@@ -482,7 +483,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                                     float pdf_light_area = 1.0f / (sc.num_lights * L.area);
                                     float pdf_light_dir = pdf_light_area * dist2 / fmaxf(cos_light, 1e-6f);
                                     f3 brdf; float pdf_bsdf;
-                                    bsdf_eval_pdf(m, ctx, wi_light, brdf, pdf_bsdf, &diffuse_pre);
+                                    bsdf_eval_pdf(m, ctx, wi_light, brdf, pdf_bsdf, &pre);
                                     float p_l = pdf_light_dir * pdf_light_dir;
                                     float p_b = pdf_bsdf * pdf_bsdf;
                                     float mis_w = p_l / fmaxf(p_l + p_b, 1e-8f);
@@ -502,7 +503,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     f3 wi = mk3(0, 0, 0), bsdf_val = mk3(0, 0, 0); float pdf_omega = 0.0f, new_eta = ray_eta; bool is_delta = false;
                     if(!last_bounce){
                         float u_rr = rng_next(rs), u1 = rng_next(rs), u2 = rng_next(rs);
-                        bsdf_sample(m, ctx, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta, &diffuse_pre);
+                        bsdf_sample(m, ctx, u_rr, u1, u2, ray_eta, wi, bsdf_val, pdf_omega, is_delta, new_eta, &pre);
                     }
                     if(!(pdf_omega <= 0.0f)){          // pt_cu.cu:214 (and the TIR return, defined: terminate)
                         f3 new_o;
