@@ -134,7 +134,15 @@ int hpt_untile(const void *d_gathered, void *d_image, int W, int H,
 
 /* One-shot equivalent of the reference's pt_render_wrapper (include/pt_cu.cuh:6-13):
  * scene_min/scene_max/light_depth/light_sample are accepted and ignored there too
- * (src/pt_cu.cu:259-262).  seed < 0 -> seed from the clock like the reference. */
+ * (src/pt_cu.cu:259-262).  seed < 0 -> seed from the clock like the reference.
+ *
+ * The reference uploads the scene and allocates its buffers on every call (src/pt_cu.cu:270-296), and
+ * its interactive front-end calls the wrapper once per frame (src/main.cpp:416).  Here the two one-shot
+ * wrappers keep the last scene (device records, BVH, workspace) and reuse it when the next call on the
+ * same device passes byte-identical light/sphere/triangle arrays; anything else rebuilds.  The images
+ * are the same either way.  hpt_wrapper_cache_clear() releases the kept scene; HPT_WRAPPER_CACHE=0 in
+ * the environment switches the reuse off. */
+void hpt_wrapper_cache_clear(void);
 int hpt_pt_render_wrapper(const void *lights, int num_lights,
                           const void *spheres, int num_spheres,
                           const void *triangles, int num_triangles,

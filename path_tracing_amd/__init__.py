@@ -79,6 +79,8 @@ def load_library() -> C.CDLL:
                      "hpt_device_count"):
             getattr(lib, name).restype = C.c_int
         lib.hpt_scene_destroy.restype = None
+        lib.hpt_wrapper_cache_clear.restype = None
+        lib.hpt_wrapper_cache_clear.argtypes = []
         lib.hpt_scene_destroy.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
@@ -204,6 +206,11 @@ class Scene:
 def untile(d_gathered_ptr: int, d_image_ptr: int, W: int, H: int, params: Params, stream: int = 0):
     """[rank][local slot] packed framebuffers -> row-major W*H image (device pointers)."""
     _check(load_library().hpt_untile(C.c_void_p(d_gathered_ptr), C.c_void_p(d_image_ptr), W, H, C.byref(params), C.c_void_p(stream)))
+
+
+def wrapper_cache_clear() -> None:
+    """Releases the scene the one-shot wrappers keep between calls (include/hpt.h)."""
+    load_library().hpt_wrapper_cache_clear()
 
 
 def pt_render_wrapper(lights, spheres, triangles, camera, W, H, eye_depth, spp, seed=-1,

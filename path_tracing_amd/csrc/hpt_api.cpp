@@ -15,8 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -536,6 +538,48 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
 
 } // namespace
 
+namespace {
+
+// the scene kept by the one-shot wrappers (include/hpt.h, hpt_pt_render_wrapper)
+struct WrapperCache { std::mutex mu; hpt_scene *scene = nullptr; int device = -1; } g_wrap;
+
+bool wrapper_cache_enabled(){
+    const char *e = getenv("HPT_WRAPPER_CACHE");
+    return !(e && e[0] == '0');
+}
+
+bool same_bytes(const std::vector<unsigned char> &kept, const void *given, size_t bytes){
+    return kept.size() == bytes && (bytes == 0 || memcmp(kept.data(), given, bytes) == 0);
+}
+
+// g_wrap.mu held.  The kept scene when the arrays are byte-identical to the ones it was built from, else a new one.
+int wrapper_scene(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt, hpt_scene **out){
+    int dev = -1;
+    if(hipGetDevice(&dev) != hipSuccess) dev = -1;
+    hpt_scene *k = g_wrap.scene;
+    if(k && wrapper_cache_enabled() && dev == g_wrap.device && nl == k->nl && ns == k->ns && nt == k->nt && nl >= 0 && ns >= 0 && nt >= 0 &&
+       same_bytes(k->h_lights, lights, (size_t) nl * HPT_LIGHT_BYTES) && same_bytes(k->h_spheres, spheres, (size_t) ns * HPT_SPHERE_BYTES) &&
+       same_bytes(k->h_tris, tris, (size_t) nt * HPT_TRIANGLE_BYTES)){
+        *out = k;
+        return HPT_OK;
+    }
+    if(k){ hpt_scene_destroy(k); g_wrap.scene = nullptr; g_wrap.device = -1; }
+    int rc = hpt_scene_create(lights, nl, spheres, ns, tris, nt, out);
+    if(rc) return rc;
+    if(wrapper_cache_enabled()){ g_wrap.scene = *out; g_wrap.device = dev; }
+    return HPT_OK;
+}
+
+// g_wrap.mu held: a scene that is not kept is destroyed (the error text of the render survives)
+void wrapper_release(hpt_scene *s){
+    if(s == g_wrap.scene) return;
+    std::string keep = g_err;
+    hpt_scene_destroy(s);
+    g_err = keep;
+}
+
+} // namespace
+
 extern "C" {
 
 const char *hpt_last_error(void){ return g_err.c_str(); }
@@ -666,19 +710,24 @@ int hpt_render_pt(hpt_scene *s, const void *camera, int W, int H, int eye_depth,
     return HPT_OK;
 }
 
+void hpt_wrapper_cache_clear(void){
+    std::lock_guard<std::mutex> lock(g_wrap.mu);
+    if(g_wrap.scene) hpt_scene_destroy(g_wrap.scene);
+    g_wrap.scene = nullptr; g_wrap.device = -1;
+}
+
 int hpt_pt_render_wrapper(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
                           const float scene_min[3], const float scene_max[3], const void *camera, float *host_image,
                           int W, int H, int light_depth, int light_sample, int eye_depth, int spp, int64_t seed){
     (void) scene_min; (void) scene_max; (void) light_depth; (void) light_sample;   // ignored by the reference too
+    std::lock_guard<std::mutex> lock(g_wrap.mu);
     hpt_scene *s = nullptr;
-    int rc = hpt_scene_create(lights, nl, spheres, ns, tris, nt, &s);
+    int rc = wrapper_scene(lights, nl, spheres, ns, tris, nt, &s);
     if(rc) return rc;
     hpt_params p; memset(&p, 0, sizeof p);
     p.seed = seed >= 0 ? (uint64_t) seed : (uint64_t) time(nullptr);      // reference: time(NULL), pt_cu.cu:282
     rc = hpt_render_pt(s, camera, W, H, eye_depth, spp, &p, host_image);
-    std::string keep = g_err;
-    hpt_scene_destroy(s);
-    g_err = keep;
+    wrapper_release(s);
     return rc;
 }
 
@@ -761,15 +810,14 @@ int hpt_bdpt_render_wrapper(const void *lights, int nl, const void *spheres, int
         float *illum = (float *) (L.data() + (size_t) i * HPT_LIGHT_BYTES + 24);
         for(int c = 0; c < 3; ++c) illum[c] = illum[c] * (float) light_sample;
     }
+    std::lock_guard<std::mutex> lock(g_wrap.mu);
     hpt_scene *s = nullptr;
-    int rc = hpt_scene_create(L.data(), nl, spheres, ns, tris, nt, &s);
+    int rc = wrapper_scene(L.data(), nl, spheres, ns, tris, nt, &s);
     if(rc) return rc;
     hpt_params p; memset(&p, 0, sizeof p);
     p.seed = seed >= 0 ? (uint64_t) seed : (uint64_t) time(nullptr);
     rc = hpt_render_bdpt(s, camera, W, H, eye_depth, light_depth, spp, spl, &p, host_image);
-    std::string keep = g_err;
-    hpt_scene_destroy(s);
-    g_err = keep;
+    wrapper_release(s);
     return rc;
 }
 

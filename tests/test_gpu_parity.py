@@ -411,3 +411,31 @@ def test_split_is_dropped_for_scenes_whose_rays_are_all_long(hpt, sio, oracle_mo
         c = scene.render_pt(cam, 64, 64, 4, 2, p)
         assert scene.stats()["split_budget"] == 6
     assert_parity(a, ref); assert_parity(b, ref); assert_parity(c, ref)
+
+
+def test_one_shot_wrappers_keep_the_scene_between_calls(hpt, sio, oracle_mod):
+    """pt_render_wrapper is called once per frame by the reference's interactive front-end (src/main.cpp:416).
+    A second call with byte-identical arrays reuses the uploaded scene (no BVH build, no allocation); a changed
+    triangle rebuilds.  The images are those of a fresh scene either way."""
+    import time
+    L, sp, tr = sio.cornell_with_sphere(20000)
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 64, 64)
+    hpt.wrapper_cache_clear()
+    t0 = time.perf_counter(); a = hpt.pt_render_wrapper(L, sp, tr, cam, 64, 64, 4, 2, seed=4); t1 = time.perf_counter()
+    b = hpt.pt_render_wrapper(L, sp, tr, cam, 64, 64, 4, 2, seed=4); t2 = time.perf_counter()
+    with hpt.Scene(L, sp, tr) as scene:
+        fresh = scene.render_pt(cam, 64, 64, 4, 2, hpt.make_params(seed=4))
+    assert np.array_equal(a, fresh) and np.array_equal(b, fresh)
+    assert (t2 - t1) < 0.5 * (t1 - t0)                     # the 20 000-triangle BVH build is gone
+    tr2 = tr.copy()
+    tr2["v0"][-1] = np.asarray(tr2["v0"][-1]) + np.float32(0.25)       # move one corner of the last triangle
+    c = hpt.pt_render_wrapper(L, sp, tr2, cam, 64, 64, 4, 2, seed=4)
+    with hpt.Scene(L, sp, tr2) as scene:
+        fresh2 = scene.render_pt(cam, 64, 64, 4, 2, hpt.make_params(seed=4))
+    assert np.array_equal(c, fresh2)
+    d = hpt.pt_render_wrapper(L, sp, tr, cam, 64, 64, 4, 2, seed=5)
+    assert not np.array_equal(d, a)                        # another seed, another image
+    hpt.wrapper_cache_clear()
+    e = hpt.pt_render_wrapper(L, sp, tr, cam, 64, 64, 4, 2, seed=4)
+    assert np.array_equal(e, fresh)
+    hpt.wrapper_cache_clear()
