@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--tris", type=int, default=100_000)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-pipeline", action="store_true", help="one pass in flight at a time (HPT_FLAG_SINGLE_PIPELINE) in every step")
+    ap.add_argument("--no-exclusive-step", action="store_true", help="skip the extra untimed single-pipeline step that measures the kernels' exclusive durations")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on a one-GPU box)")
     ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
     args = ap.parse_args()
@@ -127,13 +129,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    base_flags = hpt.FLAG_SINGLE_PIPELINE if args.single_pipeline else 0
     for _ in range(args.warmup):
-        step(0)
+        step(base_flags)
     fence()
     t0 = time.perf_counter()
     ext_ms, ext_n, tot_ms, res_ms, res_n = 0.0, 0, 0.0, 0.0, 0
     for _ in range(args.steps):
-        step(hpt.FLAG_TIME_KERNELS)        # HIP events around every launch, on the launch stream
+        step(base_flags | hpt.FLAG_TIME_KERNELS)        # HIP events around every launch, on the launch stream
         st = scene.stats()                 # waits for this rank's render
         ext_ms += st["ms_extend"] + st["ms_connect"]; ext_n += st["n_extend"] + st["n_connect"]; tot_ms += st["ms_total"]
         res_ms += st["ms_resume"]; res_n += st["n_resume"]
@@ -145,6 +148,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # untimed: the same render with one pass in flight at a time -- the kernels' durations when they have the
+    # device to themselves (in the timed steps two pipelines share it, so a launch takes longer there)
+    excl = None
+    if not args.single_pipeline and not args.no_exclusive_step:
+        step(hpt.FLAG_SINGLE_PIPELINE | hpt.FLAG_TIME_KERNELS)
+        fence()
+        excl = scene.stats()
     # untimed pass that counts the work of the same render (boxes / triangles / rays per kernel)
     step(hpt.FLAG_COUNT_WORK)
     fence()
@@ -196,8 +206,17 @@ def main():
                          "launches_per_step": launches_per_render, "split_budget": st["split_budget"],
                          "long_ray_fraction_last_pass": st["long_rays_last_pass"] / max(st["traced_rays_last_pass"], 1),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "pipelines_in_flight": 1 if args.single_pipeline else 2,
+                         "exclusive": None if excl is None else {
+                             "note": "same render, untimed, HPT_FLAG_SINGLE_PIPELINE: one pass in flight, each launch has the device to itself",
+                             "ms_per_step": excl["ms_total"],
+                             "avg_first_launch_ms": (excl["ms_extend"] + excl["ms_connect"]) / max(excl["n_extend"] + excl["n_connect"], 1),
+                             "avg_resume_launch_ms": excl["ms_resume"] / max(excl["n_resume"], 1),
+                             "achieved": bytes_per_launch / ((excl["ms_extend"] + excl["ms_connect"] + excl["ms_resume"]) / max(excl["n_extend"] + excl["n_connect"], 1) * 1e-3) / 1e9},
                          "valu_utilization_pmc": valu,
                          "note": "rank 0's kernels; bytes = 32*boxes + 36*tris + 44*closest rays + 36*shadow rays of this rank. "
+                                 "Two passes of a render are in flight on two streams, so a launch shares the device with the other pipeline's kernels "
+                                 "and its duration (hence `achieved`) is that of a shared device; `exclusive` has the single-pipeline figures. "
                                  "The BVH and triangles of this scene stay in L2 / Infinity Cache, so the algorithmic bytes are not "
                                  "HBM traffic (`traffic` is what the fabric saw, PMC) and frac can exceed 1; the kernel's binding limit "
                                  "is VALU issue (valu_utilization_pmc = SQ_INSTS_VALU x 4 cycles / SIMD cycles, from profiles/)"},

@@ -72,6 +72,8 @@ typedef struct hpt_params {
                                       * q = clamp(max throughput channel, 0.05, 1).  The reference has no
                                       * roulette: off by default; it costs one extra uniform per
                                       * bounce, so images differ from the roulette-free ones sample by sample */
+#define HPT_FLAG_SINGLE_PIPELINE 32 /* PT: one pass in flight at a time (default: two passes of a render run
+                                      * concurrently on two streams with a workspace each; same image) */
 
 typedef struct hpt_stats {
     uint64_t samples;         /* camera samples traced by the last render */

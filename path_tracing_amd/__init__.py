@@ -27,6 +27,7 @@ FLAG_COUNT_WORK = 2
 FLAG_OUTPUT_SUM = 4
 FLAG_TIME_KERNELS = 8
 FLAG_RUSSIAN_ROULETTE = 16
+FLAG_SINGLE_PIPELINE = 32
 
 
 class HptError(RuntimeError):

@@ -71,6 +71,17 @@ struct hpt_scene {
     uint32_t *queue[2] = { nullptr, nullptr };   // path queues (ping-pong)
     uint32_t *squeue = nullptr;                  // shadow queue (path slots)
     uint32_t *lqueue[2] = { nullptr, nullptr };  // rays set aside by the first trace launch: closest-hit, shadow
+    // second pipeline (PT): two passes of a render are in flight at a time, each with its own path state,
+    // queues and counters, on its own stream -- the kernels of one fill the issue slots the other leaves idle
+    struct Pipe2 {
+        size_t cap_paths = 0;
+        PathBuf pb{}; ShadowBuf sb{};
+        uint32_t *queue[2] = { nullptr, nullptr }, *squeue = nullptr, *lqueue[2] = { nullptr, nullptr };
+        uint32_t *counters = nullptr; int n_counters = 0;
+        uint32_t *h_count = nullptr;
+        hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+    } p2;
+    const uint32_t *last_counters = nullptr;     // counters of the last pass rendered (either pipeline)
     uint32_t *counters = nullptr; int n_counters = 0;
     float4 *accum = nullptr;
     WorkCounters *d_wc = nullptr;
@@ -105,6 +116,48 @@ void free_workspace(hpt_scene *s){
     hipFree(s->queue[0]); hipFree(s->queue[1]); hipFree(s->squeue); s->squeue = nullptr;
     hipFree(s->lqueue[0]); hipFree(s->lqueue[1]); s->lqueue[0] = s->lqueue[1] = nullptr;
     s->pb = PathBuf{}; s->sb = ShadowBuf{}; s->queue[0] = s->queue[1] = nullptr; s->cap_paths = 0;
+}
+
+void free_pipe2(hpt_scene *s){
+    hpt_scene::Pipe2 &w = s->p2;
+    hipFree(w.pb.org_eta); hipFree(w.pb.dir_flags); hipFree(w.pb.thr); hipFree(w.pb.col); hipFree(w.pb.rng); hipFree(w.pb.hit);
+    hipFree(w.sb.org_max); hipFree(w.sb.dir); hipFree(w.sb.contrib);
+    hipFree(w.queue[0]); hipFree(w.queue[1]); hipFree(w.squeue); hipFree(w.lqueue[0]); hipFree(w.lqueue[1]);
+    w.pb = PathBuf{}; w.sb = ShadowBuf{}; w.queue[0] = w.queue[1] = w.squeue = w.lqueue[0] = w.lqueue[1] = nullptr; w.cap_paths = 0;
+}
+
+int ensure_pipe2(hpt_scene *s, size_t paths, int n_counters){
+    hpt_scene::Pipe2 &w = s->p2;
+    if(paths > w.cap_paths){
+        free_pipe2(s);
+        HIP_TRY(hipMalloc((void **) &w.pb.org_eta, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.pb.dir_flags, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.pb.thr, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.pb.col, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.pb.rng, paths * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **) &w.pb.hit, paths * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **) &w.sb.org_max, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.sb.dir, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.sb.contrib, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **) &w.queue[0], paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &w.queue[1], paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &w.squeue, paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &w.lqueue[0], paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &w.lqueue[1], paths * sizeof(uint32_t)));
+        w.cap_paths = paths;
+    }
+    if(n_counters > w.n_counters){
+        hipFree(w.counters); w.counters = nullptr;
+        HIP_TRY(hipMalloc((void **) &w.counters, (size_t) n_counters * sizeof(uint32_t)));
+        w.n_counters = n_counters;
+    }
+    if(!w.h_count) HIP_TRY(hipHostMalloc((void **) &w.h_count, 64));
+    if(!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    if(!w.ev_fork){
+        HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+    }
+    return HPT_OK;
 }
 
 int ensure_workspace(hpt_scene *s, size_t paths, size_t n_local, int n_counters){
@@ -189,23 +242,6 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     int rc = make_tiling(W, H, &P, tl);
     if(rc) return rc;
 
-    // samples in flight per pass: about 64 Mi path slots (9 GiB of path state, queues and shadow
-    // records: nothing on a 288 GB device).  Fewer, larger passes amortise the low-occupancy tail
-    // iterations of every pass (config 3, ms per 256-spp render: 4 Mi slots 291, 8 Mi 243, 16 Mi 219,
-    // 64 Mi 196, 256 Mi 192).
-    int spass = P.samples_per_pass;
-    if(spass <= 0){
-        const long long target = 64ll << 20;
-        spass = (int) std::max<long long>(1, target / tl.n_local);
-    }
-    spass = std::min(spass, spp);
-    size_t paths = (size_t) tl.n_local * spass;
-    if(paths > 0x7FFFFFF0ull) return fail(HPT_ERR_INVALID, "too many path slots per pass");
-    int max_iters = eye_depth + P.max_delta + 1;
-    int n_counters = 4 * (max_iters + 2);
-    rc = ensure_workspace(s, paths, tl.n_local, n_counters);
-    if(rc) return rc;
-
     const float *cf = (const float *) camera;       // CudaCamera: eye, U, V, W, UL, dx, dy (12 B each)
     CameraDev cam;
     memcpy(cam.eye, cf + 0, 12); memcpy(cam.UL, cf + 12, 12); memcpy(cam.dx, cf + 15, 12); memcpy(cam.dy, cf + 18, 12);
@@ -214,7 +250,37 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     const bool count = (flags & HPT_FLAG_COUNT_WORK) != 0;
     const bool timek = (flags & HPT_FLAG_TIME_KERNELS) != 0;
     const bool brute = (flags & HPT_FLAG_BRUTE_FORCE) != 0;
+    const bool legacy = brute || (P.reserved & 1);          // separate extend/connect kernels (the scan variants)
     const int kflags = (brute ? 1 : 0) | (count ? 2 : 0);
+
+    // Samples in flight per pass: about 64 Mi path slots (9.5 GiB of path state, queues and shadow records:
+    // nothing on a 288 GB device).  Fewer, larger passes amortise the low-occupancy tail iterations of every
+    // pass (config 3, ms per 256-spp render: 4 Mi slots 291, 8 Mi 243, 16 Mi 219, 64 Mi 196, 256 Mi 192).
+    // Two passes are in flight at a time, on two streams with a workspace each: while one pipeline's kernel
+    // drains or waits on memory the other's waves take the issue slots (config 3: 167 -> 157 ms).  A render
+    // that fits one pass is cut in two for that.
+    bool dual = !(flags & HPT_FLAG_SINGLE_PIPELINE) && !count && !legacy;
+    int spass = P.samples_per_pass;
+    if(spass <= 0){
+        const long long target = 64ll << 20;
+        spass = (int) std::max<long long>(1, target / tl.n_local);
+        spass = std::min(spass, spp);
+        if(dual && spass >= spp && spp >= 2 && (long long) tl.n_local * spp >= (8ll << 20)) spass = (spp + 1) / 2;
+    }
+    spass = std::min(spass, spp);
+    const int npass = (spp + spass - 1) / spass;
+    if(npass < 2) dual = false;
+    size_t paths = (size_t) tl.n_local * spass;
+    if(paths > 0x7FFFFFF0ull) return fail(HPT_ERR_INVALID, "too many path slots per pass");
+    int max_iters = eye_depth + P.max_delta + 1;
+    int n_counters = 4 * (max_iters + 2);
+    rc = ensure_workspace(s, paths, tl.n_local, n_counters);
+    if(rc) return rc;
+    if(dual){
+        rc = ensure_pipe2(s, paths, n_counters);
+        if(rc) return rc;
+    }
+
     WorkCounters *wc = count ? s->d_wc : nullptr;
     s->timed.clear(); s->event_next = 0;
     s->last_flags = flags;
@@ -236,83 +302,131 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         }
         if(s->split_hold > 0){ split_off = true; --s->split_hold; }
     }
+    // node-step budget of the first trace launch (tuning bits 1..6: 0 = default, 0x3F = no split)
+    int budget = (P.reserved >> 1) & 0x3F;
+    budget = budget == 0 ? kTraceBudget : (budget == 0x3F ? 0 : budget);
+    if(count || legacy) budget = 0;                     // work counts are those of the plain single-launch traversal
+    int tuning = P.reserved;
+    if(auto_budget && split_off){
+        budget = 0;                                     // all rays long: single launches with the long-ray tuning
+        if(((tuning >> 16) & 0xFF) == 0) tuning |= (int) (kLongChunk / 256u) << 16;
+        if(((tuning >> 8) & 0xFF) == 0) tuning |= kLongRefillMin << 8;
+        if(((tuning >> 24) & 0x7F) == 0) tuning |= kLongNodeMin << 24;
+    }
+    s->last_budget = budget;
+    const int roulette = (flags & HPT_FLAG_RUSSIAN_ROULETTE) ? 1 : 0;
 
     HIP_TRY(hipMemsetAsync(s->d_wc, 0, sizeof(WorkCounters), stream));
     HIP_TRY(hipMemsetAsync(s->accum, 0, (size_t) tl.n_local * sizeof(float4), stream));
     HIP_TRY(hipEventRecord(s->ev_start, stream));
 
-    for(int done = 0; done < spp; done += spass){
-        int sthis = std::min(spass, spp - done);
-        uint32_t slots = (uint32_t) tl.n_local * (uint32_t) sthis;
-        HIP_TRY(hipMemsetAsync(s->counters, 0, (size_t) n_counters * sizeof(uint32_t), stream));
-        uint32_t *qcnt = s->counters;                 // qcnt[i]: paths entering iteration i
-        uint32_t *scnt = s->counters + (max_iters + 2);   // scnt[i]: shadow rays of iteration i
-        uint32_t *lecnt = s->counters + 2 * (max_iters + 2);   // lecnt[i] / lscnt[i]: rays the trace launch of
-        uint32_t *lscnt = s->counters + 3 * (max_iters + 2);   // iteration i set aside for its second launch
-        { LaunchTimer t(s, stream, timek, 3);
-          launch_generate(stream, tl, cam, s->pb, &qcnt[0], sthis,
-                          (uint32_t) (P.sample_offset + done), P.seed, wc); }
-        int cur = 0;
-        const bool legacy = brute || (P.reserved & 1);      // separate extend/connect kernels (the scan variants)
-        // node-step budget of the first trace launch (tuning bits 1..6: 0 = default, 0x3F = no split)
-        int budget = (P.reserved >> 1) & 0x3F;
-        budget = budget == 0 ? kTraceBudget : (budget == 0x3F ? 0 : budget);
-        if(count || legacy) budget = 0;                     // work counts are those of the plain single-launch traversal
-        int tuning = P.reserved;
-        if(auto_budget && split_off){
-            budget = 0;                                     // all rays long: single launches with the long-ray tuning
-            if(((tuning >> 16) & 0xFF) == 0) tuning |= (int) (kLongChunk / 256u) << 16;
-            if(((tuning >> 8) & 0xFF) == 0) tuning |= kLongRefillMin << 8;
-            if(((tuning >> 24) & 0x7F) == 0) tuning |= kLongNodeMin << 24;
-        }
-        s->last_budget = budget;
-        int pending_shadow = -1;                            // iteration whose shadow queue is not traced yet
-        for(int it = 0; it < max_iters; ++it){
-            if(it >= eye_depth && ((it - eye_depth) & 1) == 0){
-                // only free delta bounces can keep a path alive this long: look before launching,
-                // every other iteration (an empty launch costs less than a read-back)
-                HIP_TRY(hipMemcpyAsync(s->h_count, &qcnt[it], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                if(*s->h_count == 0u) break;
+    // one pass in flight on one pipeline
+    struct Pass {
+        PathBuf pb; ShadowBuf sb; uint32_t *queue[2], *squeue, *lqueue[2], *counters, *h_count; hipStream_t st;
+        int sthis = 0, cur = 0, pending_shadow = -1; uint32_t slots = 0;
+        uint32_t *qcnt, *scnt, *lecnt, *lscnt;
+    };
+    Pass pipe[2];
+    pipe[0].pb = s->pb; pipe[0].sb = s->sb; pipe[0].queue[0] = s->queue[0]; pipe[0].queue[1] = s->queue[1]; pipe[0].squeue = s->squeue;
+    pipe[0].lqueue[0] = s->lqueue[0]; pipe[0].lqueue[1] = s->lqueue[1]; pipe[0].counters = s->counters; pipe[0].h_count = s->h_count; pipe[0].st = stream;
+    if(dual){
+        hpt_scene::Pipe2 &w = s->p2;
+        pipe[1].pb = w.pb; pipe[1].sb = w.sb; pipe[1].queue[0] = w.queue[0]; pipe[1].queue[1] = w.queue[1]; pipe[1].squeue = w.squeue;
+        pipe[1].lqueue[0] = w.lqueue[0]; pipe[1].lqueue[1] = w.lqueue[1]; pipe[1].counters = w.counters; pipe[1].h_count = w.h_count; pipe[1].st = w.stream;
+    }
+    for(Pass &q : pipe){
+        q.qcnt = q.counters;                              // qcnt[i]: paths entering iteration i
+        q.scnt = q.counters + (max_iters + 2);            // scnt[i]: shadow rays of iteration i
+        q.lecnt = q.counters + 2 * (max_iters + 2);       // lecnt[i] / lscnt[i]: rays the trace launch of
+        q.lscnt = q.counters + 3 * (max_iters + 2);       // iteration i set aside for its second launch
+    }
+
+    auto begin_pass = [&](Pass &q, int done) -> int {
+        q.sthis = std::min(spass, spp - done);
+        q.slots = (uint32_t) tl.n_local * (uint32_t) q.sthis;
+        q.cur = 0; q.pending_shadow = -1;
+        HIP_TRY(hipMemsetAsync(q.counters, 0, (size_t) n_counters * sizeof(uint32_t), q.st));
+        LaunchTimer t(s, q.st, timek, 3);
+        launch_generate(q.st, tl, cam, q.pb, &q.qcnt[0], q.sthis, (uint32_t) (P.sample_offset + done), P.seed, wc);
+        return HPT_OK;
+    };
+    auto iteration = [&](Pass &q, int it){
+        const uint32_t *eq = it == 0 ? nullptr : q.queue[q.cur];
+        if(legacy){
+            LaunchTimer t(s, q.st, timek, 0);
+            launch_extend(q.st, s->sd, q.pb, eq, &q.qcnt[it], q.slots, kflags, wc);
+        } else {
+            // extension rays of this iteration + shadow rays of the previous one, one launch
+            TraceSplit split{ q.lqueue[0], &q.lecnt[it], q.lqueue[1], &q.lscnt[it], budget };
+            { LaunchTimer t(s, q.st, timek, 0);
+              launch_trace(q.st, s->sd, q.pb, q.sb, eq, &q.qcnt[it], q.slots, q.squeue,
+                           q.pending_shadow >= 0 ? &q.scnt[q.pending_shadow] : nullptr, q.slots, s->stack_levels, kflags, tuning, wc, &split); }
+            if(split.budget > 0){
+                LaunchTimer t(s, q.st, timek, 4);
+                launch_trace_resume(q.st, s->sd, q.pb, q.sb, true, q.pending_shadow >= 0, q.slots, s->stack_levels, wc, split);
             }
-            const uint32_t *eq = it == 0 ? nullptr : s->queue[cur];
-            if(legacy){
-                { LaunchTimer t(s, stream, timek, 0);
-                  launch_extend(stream, s->sd, s->pb, eq, &qcnt[it], slots, kflags, wc); }
-            } else {
-                // extension rays of this iteration + shadow rays of the previous one, one launch
-                TraceSplit split{ s->lqueue[0], &lecnt[it], s->lqueue[1], &lscnt[it], budget };
-                { LaunchTimer t(s, stream, timek, 0);
-                  launch_trace(stream, s->sd, s->pb, s->sb, eq, &qcnt[it], slots, s->squeue,
-                               pending_shadow >= 0 ? &scnt[pending_shadow] : nullptr, slots, s->stack_levels, kflags, tuning, wc, &split); }
-                if(split.budget > 0){
-                    LaunchTimer t(s, stream, timek, 4);
-                    launch_trace_resume(stream, s->sd, s->pb, s->sb, true, pending_shadow >= 0, slots, s->stack_levels, wc, split);
-                }
-                pending_shadow = -1;
-            }
-            { LaunchTimer t(s, stream, timek, 1);
-              launch_shade(stream, s->sd, s->pb, eq, &qcnt[it], slots, s->queue[cur ^ 1],
-                           &qcnt[it + 1], s->sb, s->squeue, &scnt[it], eye_depth, P.max_delta,
-                           (flags & HPT_FLAG_RUSSIAN_ROULETTE) ? 1 : 0, wc); }
-            if(legacy){
-                LaunchTimer t(s, stream, timek, 2);
-                launch_connect(stream, s->sd, s->pb, s->sb, s->squeue, &scnt[it], slots, kflags, wc);
-            } else pending_shadow = it;
-            cur ^= 1;
+            q.pending_shadow = -1;
         }
-        if(pending_shadow >= 0){
-            TraceSplit split{ s->lqueue[0], &lecnt[max_iters], s->lqueue[1], &lscnt[max_iters], budget };
-            { LaunchTimer t(s, stream, timek, 2);
-              launch_trace(stream, s->sd, s->pb, s->sb, nullptr, nullptr, 0, s->squeue, &scnt[pending_shadow], slots,
+        { LaunchTimer t(s, q.st, timek, 1);
+          launch_shade(q.st, s->sd, q.pb, eq, &q.qcnt[it], q.slots, q.queue[q.cur ^ 1],
+                       &q.qcnt[it + 1], q.sb, q.squeue, &q.scnt[it], eye_depth, P.max_delta, roulette, wc); }
+        if(legacy){
+            LaunchTimer t(s, q.st, timek, 2);
+            launch_connect(q.st, s->sd, q.pb, q.sb, q.squeue, &q.scnt[it], q.slots, kflags, wc);
+        } else q.pending_shadow = it;
+        q.cur ^= 1;
+    };
+    // iterations past eye_depth: only free delta bounces can keep a path alive this long: look before
+    // launching, every other iteration (an empty launch costs less than a read-back)
+    auto tail = [&](Pass &q) -> int {
+        for(int it = eye_depth; it < max_iters; ++it){
+            if(((it - eye_depth) & 1) == 0){
+                HIP_TRY(hipMemcpyAsync(q.h_count, &q.qcnt[it], sizeof(uint32_t), hipMemcpyDeviceToHost, q.st));
+                HIP_TRY(hipStreamSynchronize(q.st));
+                if(*q.h_count == 0u) break;
+            }
+            iteration(q, it);
+        }
+        if(q.pending_shadow >= 0){
+            TraceSplit split{ q.lqueue[0], &q.lecnt[max_iters], q.lqueue[1], &q.lscnt[max_iters], budget };
+            { LaunchTimer t(s, q.st, timek, 2);
+              launch_trace(q.st, s->sd, q.pb, q.sb, nullptr, nullptr, 0, q.squeue, &q.scnt[q.pending_shadow], q.slots,
                            s->stack_levels, kflags, tuning, wc, &split); }
             if(split.budget > 0){
-                LaunchTimer t(s, stream, timek, 4);
-                launch_trace_resume(stream, s->sd, s->pb, s->sb, false, true, slots, s->stack_levels, wc, split);
+                LaunchTimer t(s, q.st, timek, 4);
+                launch_trace_resume(q.st, s->sd, q.pb, q.sb, false, true, q.slots, s->stack_levels, wc, split);
             }
         }
+        return HPT_OK;
+    };
+
+    for(int done = 0; done < spp; done += spass * (dual ? 2 : 1)){
+        const bool second = dual && done + spass < spp;
+        if(second){
+            // the second pipeline starts after everything already queued on the caller's stream (the previous
+            // resolve of its radiance buffer included)
+            HIP_TRY(hipEventRecord(s->p2.ev_fork, stream));
+            HIP_TRY(hipStreamWaitEvent(s->p2.stream, s->p2.ev_fork, 0));
+        }
+        rc = begin_pass(pipe[0], done); if(rc) return rc;
+        if(second){ rc = begin_pass(pipe[1], done + spass); if(rc) return rc; }
+        for(int it = 0; it < eye_depth && it < max_iters; ++it){
+            iteration(pipe[0], it);
+            if(second) iteration(pipe[1], it);
+        }
+        rc = tail(pipe[0]); if(rc) return rc;
+        if(second){ rc = tail(pipe[1]); if(rc) return rc; }
+        // the per-pixel sums are added in sample order: this pass, then the other pipeline's
         { LaunchTimer t(s, stream, timek, 3);
-          launch_resolve(stream, tl, s->pb, s->accum, sthis); }
+          launch_resolve(stream, tl, pipe[0].pb, s->accum, pipe[0].sthis); }
+        s->last_counters = pipe[0].counters;
+        if(second){
+            HIP_TRY(hipEventRecord(s->p2.ev_done, s->p2.stream));
+            HIP_TRY(hipStreamWaitEvent(stream, s->p2.ev_done, 0));
+            LaunchTimer t(s, stream, timek, 3);
+            launch_resolve(stream, tl, pipe[1].pb, s->accum, pipe[1].sthis);
+            s->last_counters = pipe[1].counters;
+        }
     }
     float divisor = (flags & HPT_FLAG_OUTPUT_SUM) ? 1.0f : (float) spp;
     { LaunchTimer t(s, stream, timek, 3);
@@ -327,7 +441,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
             s->h_split_words = words;
         }
         if(!s->ev_split) HIP_TRY(hipEventCreateWithFlags(&s->ev_split, hipEventDisableTiming));
-        HIP_TRY(hipMemcpyAsync(s->h_split, s->counters, (size_t) words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(s->h_split, s->last_counters, (size_t) words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(s->ev_split, stream));
         s->split_probe_pending = true; s->split_probe_stride = max_iters + 2;
     }
@@ -354,9 +468,9 @@ int collect_stats(hpt_scene *s){
     s->stats.ms_resume = sum[4]; s->stats.n_resume = cnt[4];
     s->stats.split_budget = (uint32_t) s->last_budget;
     s->stats.traced_rays_last_pass = s->stats.long_rays_last_pass = 0;
-    if(s->last_counter_stride > 0 && s->counters && 4 * s->last_counter_stride <= s->n_counters){
+    if(s->last_counter_stride > 0 && s->last_counters){
         std::vector<uint32_t> h((size_t) 4 * s->last_counter_stride);
-        HIP_TRY(hipMemcpy(h.data(), s->counters, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h.data(), s->last_counters, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for(int i = 0; i < s->last_counter_stride; ++i){
             s->stats.traced_rays_last_pass += (uint64_t) h[i] + h[(size_t) s->last_counter_stride + i];
             s->stats.long_rays_last_pass += (uint64_t) h[(size_t) 2 * s->last_counter_stride + i] + h[(size_t) 3 * s->last_counter_stride + i];
@@ -649,6 +763,12 @@ void hpt_scene_destroy(hpt_scene *s){
     free_workspace(s);
     hipFree(s->accum); hipFree(s->counters); hipFree(s->d_wc);
     if(s->h_count) hipHostFree(s->h_count);
+    free_pipe2(s);
+    hipFree(s->p2.counters);
+    if(s->p2.h_count) hipHostFree(s->p2.h_count);
+    if(s->p2.ev_fork) hipEventDestroy(s->p2.ev_fork);
+    if(s->p2.ev_done) hipEventDestroy(s->p2.ev_done);
+    if(s->p2.stream) hipStreamDestroy(s->p2.stream);
     if(s->h_split) hipHostFree(s->h_split);
     if(s->ev_split) hipEventDestroy(s->ev_split);
     hipFree(s->d_local_own); hipFree(s->d_image_own);

@@ -5,6 +5,8 @@ src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join("profiles", "%s_kernel_stats.csv" % tag))
+for ks1 in glob.glob(os.path.join(src, "trace_single", "*", "*_kernel_stats.csv")):
+    shutil.copy(ks1, os.path.join("profiles", "%s_kernel_stats_single_pipeline.csv" % tag))
 def kname(n):
     if "k_trace<false, false>" in n: return "k_trace_first"      # first launch of a trace step (every ray, budgeted)
     if "k_trace<false, true>" in n: return "k_trace_resume"      # second launch (the rays set aside)
@@ -24,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ"):
     for k in agg:
         for cn, v in agg[k].items(): out[k][cn] = v
         out[k]["dispatches"] = len(disp[k])
-res = {"tag": tag, "workload": "bench.py --steps 1 --warmup 0 --spp 64 (cfg3 scene, 1024x1024; one 64 Mi-slot pass = the launch sizes of the 256-spp bench), one PMC counter set per run",
+res = {"tag": tag, "workload": "bench.py --steps 1 --warmup 0 --spp 64 --single-pipeline (cfg3 scene, 1024x1024; one 64 Mi-slot pass = the launch sizes of the 256-spp bench), one PMC counter set per run",
        "note": "FETCH_SIZE/WRITE_SIZE are in KiB, summed over the kernel's dispatches; on gfx950 FETCH_SIZE tallies 128-B "
                "requests as 64 B (MI355X_MICROARCH.md, HBM section): read bytes = 2 x FETCH_SIZE x 1024; counts fabric-side "
                "requests including Infinity-Cache hits", "kernels": {}}

@@ -439,3 +439,22 @@ def test_one_shot_wrappers_keep_the_scene_between_calls(hpt, sio, oracle_mod):
     e = hpt.pt_render_wrapper(L, sp, tr, cam, 64, 64, 4, 2, seed=4)
     assert np.array_equal(e, fresh)
     hpt.wrapper_cache_clear()
+
+
+def test_two_pipelines_render_the_same_image_as_one(hpt, sio):
+    """Two passes of a render are in flight at a time (two streams, a workspace each); the per-pixel sums are
+    still added in sample order, so the image is that of HPT_FLAG_SINGLE_PIPELINE -- for an even and an odd
+    number of passes, and when a one-pass render is cut in two (>= 8 Mi path slots)."""
+    L, sp, tr = sio.cornell_with_sphere(5000)
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 256, 256)
+    with hpt.Scene(L, sp, tr) as scene:
+        one = scene.render_pt(cam, 256, 256, 4, 7, hpt.make_params(seed=2, samples_per_pass=2, flags=hpt.FLAG_SINGLE_PIPELINE))
+        for spass in (1, 2, 3, 4, 7):
+            two = scene.render_pt(cam, 256, 256, 4, 7, hpt.make_params(seed=2, samples_per_pass=spass, flags=hpt.FLAG_TIME_KERNELS))
+            assert np.array_equal(one, two), spass
+        big = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 1024, 1024)
+        a = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_SINGLE_PIPELINE))
+        b = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2))           # 8 Mi slots: 2 x 4 spp
+        c = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_RUSSIAN_ROULETTE))
+        d = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_RUSSIAN_ROULETTE | hpt.FLAG_SINGLE_PIPELINE))
+    assert np.array_equal(a, b) and np.array_equal(c, d) and not np.array_equal(a, c)
