@@ -324,9 +324,9 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     struct Pass {
         PathBuf pb; ShadowBuf sb; uint32_t *queue[2], *squeue, *lqueue[2], *counters, *h_count; hipStream_t st;
         int sthis = 0, cur = 0, pending_shadow = -1; uint32_t slots = 0;
-        uint32_t *qcnt, *scnt, *lecnt, *lscnt;
+        uint32_t *qcnt = nullptr, *scnt = nullptr, *lecnt = nullptr, *lscnt = nullptr;
     };
-    Pass pipe[2];
+    Pass pipe[2]{};
     pipe[0].pb = s->pb; pipe[0].sb = s->sb; pipe[0].queue[0] = s->queue[0]; pipe[0].queue[1] = s->queue[1]; pipe[0].squeue = s->squeue;
     pipe[0].lqueue[0] = s->lqueue[0]; pipe[0].lqueue[1] = s->lqueue[1]; pipe[0].counters = s->counters; pipe[0].h_count = s->h_count; pipe[0].st = stream;
     if(dual){
@@ -335,6 +335,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         pipe[1].lqueue[0] = w.lqueue[0]; pipe[1].lqueue[1] = w.lqueue[1]; pipe[1].counters = w.counters; pipe[1].h_count = w.h_count; pipe[1].st = w.stream;
     }
     for(Pass &q : pipe){
+        if(!q.counters) continue;
         q.qcnt = q.counters;                              // qcnt[i]: paths entering iteration i
         q.scnt = q.counters + (max_iters + 2);            // scnt[i]: shadow rays of iteration i
         q.lecnt = q.counters + 2 * (max_iters + 2);       // lecnt[i] / lscnt[i]: rays the trace launch of
