@@ -1,18 +1,21 @@
 // HIP kernels of the unidirectional path-tracing hot path, written for gfx950 (MI355X):
 // a wavefront pipeline over queues of path slots
 //
-//   generate -> [ extend -> shade -> connect ]* -> resolve -> finalize
+//   generate -> [ trace -> shade ]* -> trace -> resolve -> finalize
 //
 // generate  primary rays for (pixel, sample) slots                 (reference src/pt_cu.cu:36-46)
-// extend    closest hit per queued path: spheres + light balls by scan, triangles by BVH
-//           (what it must return: reference include/geometric.cuh:327-388)
-// shade     light-hit emission, next-event estimation set-up, BSDF sampling, throughput
-//           update; survivors are compacted into the next queue with a wave64 ballot +
-//           mbcnt prefix and one atomic per wave          (reference src/pt_cu.cu:54-241)
-// connect   any-hit shadow rays; unoccluded contributions are added to the sample's radiance
-//           (reference include/geometric.cuh:293-325, src/pt_cu.cu:136-146,174-196)
+// trace     one merged launch per iteration: closest hit of every queued path (spheres + light balls
+//           by scan, triangles by BVH; what it must return: reference include/geometric.cuh:327-388)
+//           and the any-hit shadow rays of the previous iteration, whose unoccluded contributions are
+//           added to the sample's radiance (include/geometric.cuh:293-325, src/pt_cu.cu:136-146,
+//           174-196).  A trace step is two launches: every ray gets a budget of node steps, the few
+//           that need more are set aside and finished by the resume launch.
+// shade     light-hit emission, next-event estimation set-up, BSDF sampling, throughput update;
+//           survivors and shadow requests are compacted in LDS (wave64 ballot + mbcnt prefix) and
+//           flushed with one global atomic per workgroup            (reference src/pt_cu.cu:54-241)
 // resolve   per pixel, adds this pass's samples in sample order (src/pt_cu.cu:243-245)
 // finalize  mean over samples into the packed local framebuffer      (src/pt_cu.cu:248)
+// k_extend / k_connect are the one-ray-per-lane forms kept for the brute-force scan variants (tests).
 //
 // One lane owns one path for the whole launch, every (pixel, sample) owns one slot for the
 // whole pass, and sums run in a fixed order, so results do not depend on scheduling, queue
