@@ -2,7 +2,8 @@
 // the one-shot pt_render_wrapper equivalent.  Compiled with hipcc (host code only here).
 //
 // Render loop per pass (S samples of every local pixel in flight):
-//   generate -> repeat { extend, shade, connect } until the queue drains -> resolve
+//   generate -> repeat { trace, shade } until the queue drains -> trace -> resolve
+// with two passes in flight at a time on two streams (render_local).
 // Queue counters live in device memory, one slot per iteration, so the host issues the first
 // eye_depth iterations without ever reading the device back; only scenes whose paths are still
 // alive after that (chains of free delta bounces, reference src/pt_cu.cu:228) cost one

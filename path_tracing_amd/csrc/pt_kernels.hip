@@ -31,21 +31,7 @@ HPT_DEV uint32_t f2u(float f){ return __float_as_uint(f); }
 HPT_DEV float u2f(uint32_t u){ return __uint_as_float(u); }
 HPT_DEV f3 xyz(float4 v){ return mk3(v.x, v.y, v.z); }
 
-// ---- wave64 queue push: ballot, mbcnt prefix, one atomic per wave ------------------------
-HPT_DEV uint32_t wave_push(bool want, uint32_t *counter){
-    unsigned long long mask = __ballot(want);
-    if(mask == 0ull) return 0u;
-    uint32_t lo = (uint32_t) mask, hi = (uint32_t) (mask >> 32);
-    uint32_t prefix = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-    uint32_t total = (uint32_t) __popcll(mask);
-    uint32_t base = 0u;
-    int leader = __ffsll((long long) mask) - 1;
-    if((int) (threadIdx.x & 63u) == leader) base = atomicAdd(counter, total);
-    base = (uint32_t) __shfl((int) base, leader, 64);
-    return base + prefix;
-}
-
-// same prefix, reserving in a workgroup-local LDS counter
+// ---- wave64 queue push: ballot, mbcnt prefix, one atomic per wave on a workgroup-local LDS counter ----
 HPT_DEV uint32_t lds_push(bool want, uint32_t *lds_counter){
     unsigned long long mask = __ballot(want);
     if(mask == 0ull) return 0u;
