@@ -49,7 +49,7 @@ HPT_DEV bool tile_to_pixel(const Tiling &tl, uint32_t p, int &x, int &y){
     uint32_t lt = p / ts2, q = p % ts2;
     uint32_t gt = lt * (uint32_t) tl.world + (uint32_t) tl.rank;
     if(gt >= (uint32_t) tl.ntiles) return false;
-    uint32_t tx = gt % (uint32_t) tl.tiles_x, ty = gt / (uint32_t) tl.tiles_x;
+    uint32_t ty = gt / (uint32_t) tl.tiles_x, tx = (gt % (uint32_t) tl.tiles_x + ty) % (uint32_t) tl.tiles_x;   // rows rotated, as in pt_kernels.hip
     uint32_t sub = q >> 6, l = q & 63u;
     uint32_t spr = (uint32_t) tl.tile >> 3;
     uint32_t bx = sub % spr, by = sub / spr;

@@ -51,7 +51,10 @@ HPT_DEV bool tile_to_pixel(const Tiling &tl, uint32_t p, int &x, int &y){
     uint32_t lt = p / ts2, q = p % ts2;
     uint32_t gt = lt * (uint32_t) tl.world + (uint32_t) tl.rank;
     if(gt >= (uint32_t) tl.ntiles) return false;
-    uint32_t tx = gt % (uint32_t) tl.tiles_x, ty = gt / (uint32_t) tl.tiles_x;
+    // tile gt sits in row gt / tiles_x at column (gt % tiles_x + row) % tiles_x: every row is rotated by its
+    // index, so the tiles of one rank run down the image diagonally instead of in columns (an object that
+    // fills a few tile columns would otherwise load only the ranks owning them)
+    uint32_t ty = gt / (uint32_t) tl.tiles_x, tx = (gt % (uint32_t) tl.tiles_x + ty) % (uint32_t) tl.tiles_x;
     uint32_t sub = q >> 6, l = q & 63u;
     uint32_t spr = (uint32_t) tl.tile >> 3;
     uint32_t bx = sub % spr, by = sub / spr;
@@ -615,7 +618,7 @@ void k_untile(Tiling tl, const float *gathered, float *image){
     uint32_t x = idx % (uint32_t) tl.W, y = idx / (uint32_t) tl.W;
     uint32_t ts = (uint32_t) tl.tile;
     uint32_t tx = x / ts, ty = y / ts;
-    uint32_t gt = ty * (uint32_t) tl.tiles_x + tx;
+    uint32_t gt = ty * (uint32_t) tl.tiles_x + (tx + (uint32_t) tl.tiles_x - ty % (uint32_t) tl.tiles_x) % (uint32_t) tl.tiles_x;   // inverse of tile_to_pixel's row rotation
     uint32_t r = gt % (uint32_t) tl.world, lt = gt / (uint32_t) tl.world;
     uint32_t bx = (x % ts) >> 3, by = (y % ts) >> 3;
     uint32_t l = ((y & 7u) << 3) | (x & 7u);

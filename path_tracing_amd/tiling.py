@@ -1,7 +1,9 @@
 """Image-tile partition of the framebuffer across devices (host-side mirror).
 
-The image is cut into tile x tile squares numbered in raster order; device `rank` of `world`
-renders tiles rank, rank+world, ... into a packed local framebuffer.  Inside a tile, slots
+The image is cut into tile x tile squares numbered row by row, every row rotated by its index (tile g
+sits in row g // tiles_x at column (g % tiles_x + row) % tiles_x); device `rank` of `world` renders
+tiles rank, rank+world, ... into a packed local framebuffer, which spreads its tiles diagonally over
+the image instead of in columns.  Inside a tile, slots
 run over 8x8 pixel blocks (one wave64 of primary rays = one 8x8 block).  Every rank's local
 buffer has the same size ceil(ntiles/world) * tile^2 so the gather is a plain fixed-size
 collective; slots past the image edge or past the last tile stay zero.
@@ -31,7 +33,8 @@ def local_to_pixel(W: int, H: int, tile: int, rank: int, world: int):
     ts2 = tile * tile
     lt, q = p // ts2, p % ts2
     gt = lt * world + rank
-    tx, ty = gt % tiles_x, gt // tiles_x
+    ty = gt // tiles_x
+    tx = (gt % tiles_x + ty) % tiles_x          # every tile row is rotated by its index (diagonal stripes per rank)
     sub, l = q >> 6, q & 63
     spr = tile >> 3
     bx, by = sub % spr, sub // spr
