@@ -258,15 +258,15 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     // nothing on a 288 GB device).  Fewer, larger passes amortise the low-occupancy tail iterations of every
     // pass (config 3, ms per 256-spp render: 4 Mi slots 291, 8 Mi 243, 16 Mi 219, 64 Mi 196, 256 Mi 192).
     // Two passes are in flight at a time, on two streams with a workspace each: while one pipeline's kernel
-    // drains or waits on memory the other's waves take the issue slots (config 3: 167 -> 157 ms).  A render
-    // that fits one pass is cut in two for that.
+    // drains or waits on memory the other's waves take the issue slots (config 3: 167 -> 160 ms).  A render
+    // that fits one pass stays one pass: two concurrent half-size passes are no faster than it (64 Mi slots:
+    // 43.9 vs 42.1 ms; 32 Mi: 22.8 vs 22.6).
     bool dual = !(flags & HPT_FLAG_SINGLE_PIPELINE) && !count && !legacy;
     int spass = P.samples_per_pass;
     if(spass <= 0){
         const long long target = 64ll << 20;
         spass = (int) std::max<long long>(1, target / tl.n_local);
         spass = std::min(spass, spp);
-        if(dual && spass >= spp && spp >= 2 && (long long) tl.n_local * spp >= (8ll << 20)) spass = (spp + 1) / 2;
     }
     spass = std::min(spass, spp);
     const int npass = (spp + spass - 1) / spass;

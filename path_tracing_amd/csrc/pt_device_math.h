@@ -147,12 +147,11 @@ HPT_DEV float ggx_lambda(f3 w, float alpha){
 HPT_DEV float ggx_G(f3 wo, f3 wi, float alpha){
     return 1.0f / (1.0f + ggx_lambda(wo, alpha) + ggx_lambda(wi, alpha));
 }
-HPT_DEV f3 sample_visible_normal(f3 wo, float alpha, float u1, float u2){
+// r = sqrt(u1) and (sn, cs) = sincos(2 pi u2) come from the caller: the cosine-lobe sample uses the same two
+HPT_DEV f3 sample_visible_normal(f3 wo, float alpha, float r, float sn, float cs){
     f3 V = normalize3(mk3(alpha * wo.x, alpha * wo.y, wo.z));
     f3 T1 = (V.z < 0.9999f) ? normalize3(cross3(mk3(0, 0, 1), V)) : mk3(1, 0, 0);
     f3 T2 = cross3(V, T1);
-    float r = sqrtf(u1);
-    float sn, cs; sincos_2pi(u2, sn, cs);
     float t1 = r * cs;
     float t2 = r * sn;
     float s = 0.5f * (1.0f + V.z);
@@ -258,14 +257,16 @@ HPT_DEV void bsdf_sample(const Mat &m, const ShadeCtx &c, float u_rr, float u1, 
     }
     float alpha = roughness_to_alpha(m.roughness);
     float spec_weight = m.metallic > 0.0f ? 1.0f : 0.5f;
+    // both lobes start from the same disk point (geometric.cuh:205-207 and :393-396); computed once, ahead of
+    // the branch the lanes of a wave split on
+    float r = sqrtf(u1);
+    float sn, cs; sincos_2pi(u2, sn, cs);
     if(u_rr < spec_weight){
-        f3 wh = sample_visible_normal(wo.z > 0 ? wo : wo * -1.0f, alpha, u1, u2);
+        f3 wh = sample_visible_normal(wo.z > 0 ? wo : wo * -1.0f, alpha, r, sn, cs);
         if(wo.z < 0.0f) wh = wh * -1.0f;
         wi = reflect3(wo * -1.0f, wh);
         if(wo.z * wi.z <= 0.0f){ pdf = 0.0f; return; }
     } else {
-        float r = sqrtf(u1);
-        float sn, cs; sincos_2pi(u2, sn, cs);
         wi = mk3(r * cs, r * sn, sqrtf(fmaxf(0.0f, 1.0f - u1)));
         if(wo.z < 0.0f) wi.z *= -1.0f;
     }

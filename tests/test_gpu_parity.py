@@ -444,7 +444,7 @@ def test_one_shot_wrappers_keep_the_scene_between_calls(hpt, sio, oracle_mod):
 def test_two_pipelines_render_the_same_image_as_one(hpt, sio):
     """Two passes of a render are in flight at a time (two streams, a workspace each); the per-pixel sums are
     still added in sample order, so the image is that of HPT_FLAG_SINGLE_PIPELINE -- for an even and an odd
-    number of passes, and when a one-pass render is cut in two (>= 8 Mi path slots)."""
+    number of passes, at a size where the passes are large (8 Mi slots in two passes)."""
     L, sp, tr = sio.cornell_with_sphere(5000)
     cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 256, 256)
     with hpt.Scene(L, sp, tr) as scene:
@@ -454,7 +454,7 @@ def test_two_pipelines_render_the_same_image_as_one(hpt, sio):
             assert np.array_equal(one, two), spass
         big = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 1024, 1024)
         a = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_SINGLE_PIPELINE))
-        b = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2))           # 8 Mi slots: 2 x 4 spp
-        c = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_RUSSIAN_ROULETTE))
+        b = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, samples_per_pass=4))           # 2 x 4 Mi slots
+        c = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, samples_per_pass=3, flags=hpt.FLAG_RUSSIAN_ROULETTE))
         d = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_RUSSIAN_ROULETTE | hpt.FLAG_SINGLE_PIPELINE))
     assert np.array_equal(a, b) and np.array_equal(c, d) and not np.array_equal(a, c)
