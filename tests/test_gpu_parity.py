@@ -458,3 +458,29 @@ def test_two_pipelines_render_the_same_image_as_one(hpt, sio):
         c = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, samples_per_pass=3, flags=hpt.FLAG_RUSSIAN_ROULETTE))
         d = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_RUSSIAN_ROULETTE | hpt.FLAG_SINGLE_PIPELINE))
     assert np.array_equal(a, b) and np.array_equal(c, d) and not np.array_equal(a, c)
+
+
+def test_bdpt_virtual_ranks_assemble_bitwise(hpt, sio, oracle_mod):
+    """The bidirectional estimator shards by image tile like the PT path: G virtual ranks rendered back to
+    back and un-tiled give the single-device image bit for bit (every rank traces the same light subpaths
+    from the shared seed)."""
+    import torch
+    sc = sio.load_scene(os.path.join(GOLDEN, "scenes", "input.txt"))
+    L, sp, tr = sio.flatten_for_pt(sc)
+    order = oracle_mod.object_order(sc)
+    W, H, spp, spl = 52, 40, 2, 4
+    cam = sio.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, W, H, tan_in_float=True)
+    stream = torch.cuda.current_stream().cuda_stream
+    with hpt.Scene(L, sp, tr) as scene:
+        scene.set_groups(*order)
+        ref = scene.render_bdpt(cam, W, H, 4, 4, spp, spl, hpt.make_params(seed=21))
+        for world, tile in ((2, 32), (3, 16), (8, 8)):
+            n_local = hpt.local_pixels(W, H, hpt.make_params(world=world, tile=tile))
+            gathered = torch.zeros((world, n_local, 3), dtype=torch.float32, device="cuda")
+            for r in range(world):
+                p = hpt.make_params(seed=21, rank=r, world=world, tile=tile)
+                scene.render_bdpt_device(cam, W, H, 4, 4, spp, spl, p, gathered[r].data_ptr(), stream)
+            image = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+            hpt.untile(gathered.data_ptr(), image.data_ptr(), W, H, hpt.make_params(world=world, tile=tile), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(image.cpu().numpy(), ref), "world=%d" % world
