@@ -314,8 +314,8 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     // queue: same-address global atomics saturate near 88 per microsecond on this chip.
     __shared__ uint32_t s_next[kShadeChunk];
     __shared__ uint32_t s_shadow[kShadeChunk];
-    __shared__ uint32_t s_cnt[5];          // [0] survivors, [1] shadow requests, [2],[3] global bases, [4] survivors listed from the back
-    if(threadIdx.x < 5) s_cnt[threadIdx.x] = 0u;
+    __shared__ uint32_t s_cnt[4];          // [0] survivors, [1] shadow requests, [2],[3] global bases
+    if(threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
     const bool mats_in_lds = sc.num_mats <= kLdsMats;
     const bool lights_in_lds = sc.num_lights <= kLdsLights;
     if(mats_in_lds){
@@ -341,7 +341,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     uint32_t iters = 0;
     for(uint32_t base = begin; base < end; base += kBlock){
         uint32_t i = base + threadIdx.x;
-        bool alive = false, want_shadow = false, more_bounces = false;
+        bool alive = false, want_shadow = false;
         uint32_t path = 0;
         f3 s_p1 = mk3(0, 0, 0), s_p2 = mk3(0, 0, 0), s_contrib = mk3(0, 0, 0);
         if(i < count){
@@ -523,7 +523,6 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                             alive = alive && depth < max_depth;
                         }
                         if(alive){
-                            more_bounces = depth + 1 < max_depth;        // its next non-delta hit is not its last bounce
                             uint32_t nf = (last_is_delta ? 1u : 0u) | ((uint32_t) depth << 8) | ((uint32_t) delta_count << 16);
                             pb.org_eta[path] = make_float4(new_o.x, new_o.y, new_o.z, ray_eta);
                             pb.dir_flags[path] = make_float4(wi.x, wi.y, wi.z, u2f(nf));
@@ -544,24 +543,16 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
         }
         uint32_t spos = lds_push(want_shadow, &s_cnt[1]);
         if(want_shadow) s_shadow[spos] = path;
-        // Survivors whose next hit is (delta materials aside) their last bounce go to the front of this
-        // workgroup's stretch of the next queue, the others to its back: the waves of the next k_shade launch
-        // are then nearly all of one kind, and a wave of last bounces skips the BSDF sampling code altogether
-        // (free delta bounces leave a few paths one bounce behind the rest; mixed into every wave they would
-        // keep that code running for two or three lanes).
-        uint32_t qpos = lds_push(alive && !more_bounces, &s_cnt[0]);
-        if(alive && !more_bounces) s_next[qpos] = path;
-        uint32_t bpos = lds_push(alive && more_bounces, &s_cnt[4]);
-        if(alive && more_bounces) s_next[kShadeChunk - 1 - bpos] = path;
+        uint32_t qpos = lds_push(alive, &s_cnt[0]);
+        if(alive) s_next[qpos] = path;
     }
     __syncthreads();
     if(threadIdx.x == 0){
-        s_cnt[2] = (s_cnt[0] + s_cnt[4]) ? atomicAdd(next_count, s_cnt[0] + s_cnt[4]) : 0u;
+        s_cnt[2] = s_cnt[0] ? atomicAdd(next_count, s_cnt[0]) : 0u;
         s_cnt[3] = s_cnt[1] ? atomicAdd(scount, s_cnt[1]) : 0u;
     }
     __syncthreads();
     for(uint32_t k = threadIdx.x; k < s_cnt[0]; k += kBlock) next_queue[s_cnt[2] + k] = s_next[k];
-    for(uint32_t k = threadIdx.x; k < s_cnt[4]; k += kBlock) next_queue[s_cnt[2] + s_cnt[0] + k] = s_next[kShadeChunk - 1 - k];
     for(uint32_t k = threadIdx.x; k < s_cnt[1]; k += kBlock) squeue[s_cnt[3] + k] = s_shadow[k];
     if(wc){
         unsigned long long v = iters;
