@@ -484,3 +484,78 @@ def test_bdpt_virtual_ranks_assemble_bitwise(hpt, sio, oracle_mod):
             hpt.untile(gathered.data_ptr(), image.data_ptr(), W, H, hpt.make_params(world=world, tile=tile), stream)
             torch.cuda.synchronize()
             assert np.array_equal(image.cpu().numpy(), ref), "world=%d" % world
+
+
+def _random_scene(sio, seed):
+    """Seeded random scene in the Cornell box: 40-200 triangles of every material class (diffuse, rough
+    dielectric-opaque, rough and mirror conductors, glass), 0-3 spheres, 1-3 lights (cone, point-like,
+    parallel)."""
+    from path_tracing_amd.layouts import SPHERE
+    rng = np.random.default_rng(seed)
+    palette = [(0.7, 0.7, 0.7, 1.0, 0.0, 0.0), (0.8, 0.3, 0.2, 0.5, 0.0, 0.0), (0.9, 0.8, 0.3, 0.3, 0.9, 0.0),
+               (0.95, 0.95, 0.95, 0.0, 1.0, 0.0), (1.0, 1.0, 1.0, 0.0, 0.0, 1.5), (0.2, 0.6, 0.9, 0.05, 0.0, 0.0)]
+    rows = [t for _, tl in sio._CORNELL_WALLS for t in tl]
+    mats = [m6 for m6, tl in sio._CORNELL_WALLS for _ in tl]
+    n = int(rng.integers(40, 200))
+    c = rng.uniform([-0.4, -0.4, -0.1], [0.4, 0.4, 0.9], size=(n, 1, 3))
+    v = (c + rng.uniform(-0.12, 0.12, size=(n, 3, 3))).reshape(n, 9)
+    rows += [tuple(r) for r in v.astype(np.float32)]
+    mats += [palette[int(k)] for k in rng.integers(0, len(palette), size=n)]
+    tris = sio._tris_from(rows, mats)
+    ns = int(rng.integers(0, 4))
+    spheres = np.zeros(ns, SPHERE)
+    for k in range(ns):
+        m = palette[int(rng.integers(0, len(palette)))]
+        spheres[k]["center"] = rng.uniform([-0.3, -0.3, 0.0], [0.3, 0.3, 0.8]); spheres[k]["r"] = rng.uniform(0.05, 0.15)
+        spheres[k]["mtl"]["base_color"] = m[0:3]; spheres[k]["mtl"]["roughness"] = m[3]
+        spheres[k]["mtl"]["metallic"] = m[4]; spheres[k]["mtl"]["eta"] = m[5]; spheres[k]["id"] = k
+    lights = []
+    for k in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 3))
+        pos = tuple(rng.uniform([-0.3, 0.2, 0.0], [0.3, 0.45, 0.8]))
+        if kind == 2:
+            lights.append(sio._one_light(pos, (0.2, -1.0, 0.1), (0.6, 0.6, 0.6), 0.0, 1, 0.05))      # parallel
+        else:
+            lights.append(sio._one_light(pos, (0.0, -1.0, 0.1), tuple(rng.uniform(0.5, 1.5, size=3)), 180.0 if kind == 0 else 40.0, 0, float(rng.uniform(0.03, 0.1))))
+    return np.concatenate(lights), spheres, tris
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_random_scenes_match_the_oracle(hpt, sio, oracle_mod, seed):
+    """Unstructured scenes with every material and light class: the default render path (split trace steps,
+    two pipelines when there are two passes) equals the oracle bit for bit; so does the one-shot wrapper."""
+    L, sp, tr = _random_scene(sio, seed)
+    W, H, depth, spp = 48, 40, 5, 3
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, W, H)
+    ref, st = oracle_mod.pt_render(L, sp, tr, cam, W, H, depth, spp, seed=seed)
+    with hpt.Scene(L, sp, tr) as scene:
+        img = scene.render_pt(cam, W, H, depth, spp, hpt.make_params(seed=seed, flags=hpt.FLAG_COUNT_WORK))
+        gs = scene.stats()
+        two = scene.render_pt(cam, W, H, depth, spp, hpt.make_params(seed=seed, samples_per_pass=2))
+    assert_parity(img, ref)
+    assert np.array_equal(img, ref) and np.array_equal(two, ref)
+    assert gs["closest_rays"] == st["closest_rays"] and gs["shadow_rays"] == st["shadow_rays"]
+    one_shot = hpt.pt_render_wrapper(L, sp, tr, cam, W, H, depth, spp, seed=seed)
+    assert np.array_equal(one_shot, ref)
+    hpt.wrapper_cache_clear()
+
+
+@pytest.mark.parametrize("seed", [201, 202, 203])
+def test_random_scenes_bdpt_match_the_oracle(hpt, sio, oracle_mod, seed):
+    """The same kind of scene through the bidirectional estimator (one group: spheres, then triangles)."""
+    L, sp, tr = _random_scene(sio, seed)
+    W, H, spp, spl = 32, 24, 2, 2
+    order = (np.concatenate([np.zeros(len(sp), np.int32), np.ones(len(tr), np.int32)]),
+             np.concatenate([np.arange(len(sp), dtype=np.int32), np.arange(len(tr), dtype=np.int32)]),
+             np.zeros(len(sp) + len(tr), np.int32))
+    ref = oracle_mod.bdpt_render(L, sp, tr, order, sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, W, H, 4, 4, spp, spl, seed=seed)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, W, H, tan_in_float=True)
+    with hpt.Scene(L, sp, tr) as scene:
+        scene.set_groups(*order)
+        img = scene.render_bdpt(cam, W, H, 4, 4, spp, spl, hpt.make_params(seed=seed))
+        nog = None
+    with hpt.Scene(L, sp, tr) as scene:            # no grouping handed over = the same single group
+        nog = scene.render_bdpt(cam, W, H, 4, 4, spp, spl, hpt.make_params(seed=seed))
+    assert_parity(img, ref)
+    assert np.array_equal(img, ref) and np.array_equal(nog, ref)
