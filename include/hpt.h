@@ -179,6 +179,38 @@ int hpt_bdpt_render_wrapper(const void *lights, int num_lights, const void *sphe
 
 int hpt_get_stats(const hpt_scene *scene, hpt_stats *out);
 
+/* ---- multi-device fan-out inside the blocking call -----------------------------------------------
+ * The reference's launch API is one blocking call per frame (run_cuda_pt -> pt_render_wrapper, reference
+ * src/pt_cu_helper.cpp:66-77, src/pt_cu.cu:255-297, one device).  hpt_multi_* is the same call over the
+ * devices of one node, in ONE process: the scene is flattened and its BVH built once and uploaded to every
+ * device; every device renders its image tiles (hpt_params.rank/world are set internally) on its own
+ * stream, driven by its own host thread; the packed local framebuffers are gathered on device_ids[0] with
+ * one ncclGather per device inside one RCCL group (librccl.so is dlopen'ed on first use; each sender uses
+ * its own xGMI link to the root), un-tiled there and copied to host_image.  The image is bit-identical to
+ * hpt_render_pt's for any number of devices.
+ *   device_ids   num_devices HIP device ordinals, NULL = 0 .. num_devices-1; num_devices <= 0 = all visible
+ *   exchange     0 = RCCL (distinct devices; fails if RCCL cannot be loaded or initialised)
+ *                1 = hipMemcpyPeerAsync into the root's buffer (boxes without RCCL; tests that place
+ *                    several ranks on one device, which an RCCL communicator refuses)
+ * hpt_wrapper_set_devices(n) (or HPT_DEVICES=n in the environment, read once) makes the two one-shot
+ * wrappers -- hence the reference's unmodified run_cuda_pt / run_cuda_bdpt -- render on n devices this way;
+ * 0 returns to the environment's value, 1 to a single device. */
+typedef struct hpt_multi hpt_multi;
+int hpt_multi_create(const void *lights, int num_lights, const void *spheres, int num_spheres,
+                     const void *triangles, int num_triangles,
+                     const int *device_ids, int num_devices, int exchange, hpt_multi **out);
+void hpt_multi_destroy(hpt_multi *multi);
+int hpt_multi_num_devices(const hpt_multi *multi);
+int hpt_multi_set_groups(hpt_multi *multi, const int32_t *obj_kind, const int32_t *obj_index,
+                         const int32_t *obj_group, int num_objects);
+int hpt_multi_render_pt(hpt_multi *multi, const void *camera, int W, int H, int eye_depth, int spp,
+                        const hpt_params *params, float *host_image);
+int hpt_multi_render_bdpt(hpt_multi *multi, const void *camera, int W, int H, int eye_depth, int light_depth,
+                          int spp, int spl, const hpt_params *params, float *host_image);
+/* device time of every rank's render (HIP events), of the exchange step, and host wall time of the last call */
+int hpt_multi_get_timing(const hpt_multi *multi, double *render_ms_per_device, double *gather_ms, double *total_ms);
+int hpt_wrapper_set_devices(int num_devices);
+
 /* Ray-level probes of the intersection kernels (tests): n rays, origins/directions as
  * packed float3.  prim is the reference scan ordinal (spheres, then light balls, then
  * triangles in input order), -1 on a miss; t is 1e20f on a miss. */

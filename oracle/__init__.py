@@ -142,27 +142,6 @@ class BdptStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
-def object_order(scene_desc=None, spheres=None, tris=None):
-    """(kind, index, group) arrays: the scene file's insertion order per group when a parsed
-    SceneDesc is given, otherwise spheres then triangles in one group."""
-    kind, index, group = [], [], []
-    if scene_desc is not None:
-        ns = nt = 0
-        for gid in sorted(scene_desc.groups):
-            for obj in scene_desc.groups[gid]:
-                if obj[0] == "S":
-                    kind.append(0); index.append(ns); ns += 1
-                else:
-                    kind.append(1); index.append(nt); nt += 1
-                group.append(gid)
-    else:
-        for i in range(len(spheres)):
-            kind.append(0); index.append(i); group.append(0)
-        for i in range(len(tris)):
-            kind.append(1); index.append(i); group.append(0)
-    return (np.asarray(kind, np.int32), np.asarray(index, np.int32), np.asarray(group, np.int32))
-
-
 def bdpt_render(lights, spheres, tris, order, eye, look_at, view_up, fov_deg, W, H, eye_depth=4, light_depth=4,
                 spp=4, spl=8, *, seed=1, rng_mode=0, threads=0, window=None, rows=None, max_delta=0):
     """The cpu_bdpt estimator (restates src/cpu_bdpt.cpp:173-488).  rng_mode=1 replays the

@@ -77,12 +77,15 @@ def load_library() -> C.CDLL:
         for name in ("hpt_scene_create", "hpt_render_pt", "hpt_render_pt_device", "hpt_untile", "hpt_scene_set_groups",
                      "hpt_render_bdpt", "hpt_render_bdpt_device", "hpt_bdpt_render_wrapper",
                      "hpt_pt_render_wrapper", "hpt_get_stats", "hpt_trace_closest", "hpt_trace_visibility",
-                     "hpt_device_count"):
+                     "hpt_device_count", "hpt_multi_create", "hpt_multi_num_devices", "hpt_multi_set_groups",
+                     "hpt_multi_render_pt", "hpt_multi_render_bdpt", "hpt_multi_get_timing", "hpt_wrapper_set_devices"):
             getattr(lib, name).restype = C.c_int
         lib.hpt_scene_destroy.restype = None
         lib.hpt_wrapper_cache_clear.restype = None
         lib.hpt_wrapper_cache_clear.argtypes = []
         lib.hpt_scene_destroy.argtypes = [C.c_void_p]
+        lib.hpt_multi_destroy.restype = None
+        lib.hpt_multi_destroy.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -202,6 +205,73 @@ class Scene:
         vis = np.empty(n, np.int32)
         _check(self._lib.hpt_trace_visibility(self._h, _vp(a), _vp(b), n, FLAG_BRUTE_FORCE if brute_force else 0, _vp(vis)))
         return vis
+
+
+class MultiScene:
+    """The blocking render call fanned out over the devices of one node inside ONE process (include/hpt.h,
+    hpt_multi_*): scene and BVH built once and uploaded to every device, image tiles per device, RCCL gather
+    on the first device (exchange=0) or peer copies (exchange=1; the only mode that accepts several ranks on
+    one device).  Same results as Scene.render_pt / render_bdpt, bit for bit."""
+
+    def __init__(self, lights, spheres, triangles, device_ids=None, num_devices=0, exchange=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        lights = np.ascontiguousarray(lights, LIGHT)
+        spheres = np.ascontiguousarray(spheres, SPHERE)
+        triangles = np.ascontiguousarray(triangles, TRIANGLE)
+        ids = None
+        if device_ids is not None:
+            ids = np.ascontiguousarray(device_ids, np.int32)
+            num_devices = len(ids)
+        _check(self._lib.hpt_multi_create(_vp(lights), len(lights), _vp(spheres), len(spheres), _vp(triangles), len(triangles),
+                                          _vp(ids), int(num_devices), int(exchange), C.byref(self._h)))
+        self.num_devices = int(self._lib.hpt_multi_num_devices(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.hpt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_groups(self, kind, index, group):
+        k = np.ascontiguousarray(kind, np.int32); i = np.ascontiguousarray(index, np.int32); g = np.ascontiguousarray(group, np.int32)
+        _check(self._lib.hpt_multi_set_groups(self._h, _vp(k), _vp(i), _vp(g), len(k)))
+
+    def render_pt(self, camera, W, H, eye_depth=4, spp=8, params: Params | None = None) -> np.ndarray:
+        params = params or make_params()
+        cam = np.ascontiguousarray(camera, CAMERA)
+        img = np.empty((H, W, 3), np.float32)
+        _check(self._lib.hpt_multi_render_pt(self._h, _vp(cam.reshape(1)), W, H, eye_depth, spp, C.byref(params), _vp(img)))
+        return img
+
+    def render_bdpt(self, camera, W, H, eye_depth=4, light_depth=4, spp=8, spl=8, params: Params | None = None) -> np.ndarray:
+        params = params or make_params()
+        cam = np.ascontiguousarray(camera, CAMERA)
+        img = np.empty((H, W, 3), np.float32)
+        _check(self._lib.hpt_multi_render_bdpt(self._h, _vp(cam.reshape(1)), W, H, eye_depth, light_depth, spp, spl, C.byref(params), _vp(img)))
+        return img
+
+    def timing(self) -> dict:
+        per = (C.c_double * self.num_devices)()
+        g = C.c_double(); t = C.c_double()
+        _check(self._lib.hpt_multi_get_timing(self._h, per, C.byref(g), C.byref(t)))
+        return {"render_ms_per_device": list(per), "gather_ms": g.value, "total_ms": t.value}
+
+
+def wrapper_set_devices(n: int) -> None:
+    """Number of devices the one-shot wrappers (pt_render_wrapper / bdpt_render_wrapper) fan out over."""
+    _check(load_library().hpt_wrapper_set_devices(int(n)))
 
 
 def untile(d_gathered_ptr: int, d_image_ptr: int, W: int, H: int, params: Params, stream: int = 0):

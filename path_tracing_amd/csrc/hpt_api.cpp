@@ -20,10 +20,15 @@
 #include <cstring>
 #include <ctime>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
 using namespace hpt;
+
+namespace hpt {   // hpt_multi.cpp
+bool multi_matches(const hpt_multi *m, int n_devices, const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt);
+}
 
 namespace {
 
@@ -32,7 +37,7 @@ thread_local std::string g_err;
 int fail(int code, const std::string &msg){ g_err = msg; return code; }
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) \
-    return fail(HPT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while(0)
+    return fail(e_ == hipErrorOutOfMemory ? HPT_ERR_NOMEM : HPT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while(0)
 
 template <typename T>
 hipError_t upload(const std::vector<T> &v, T **dptr){
@@ -43,6 +48,13 @@ hipError_t upload(const std::vector<T> &v, T **dptr){
     if(!v.empty()) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     return e;
 }
+
+struct DevBuf {              // device allocation released on every return path
+    void *p = nullptr;
+    ~DevBuf(){ if(p) hipFree(p); }
+    hipError_t alloc(size_t bytes){ return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T *as() const { return (T *) p; }
+};
 
 struct TimedLaunch { hipEvent_t a, b; int cls; };
 constexpr int kSplitHold = 15;
@@ -558,8 +570,12 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
     if(rc) return rc;
     s->last_counter_stride = 0; s->last_budget = 0;
 
+    // light vertices: nl * spl subpaths of light_depth vertices each; the contribution table holds one 16-B entry
+    // per (path slot, light vertex) pair and at least one image's worth of slots, so it is bounded here
+    const long long n_lv64 = (long long) s->nl * spl * light_depth;
+    if(n_lv64 > (1ll << 24)) return fail(HPT_ERR_INVALID, "too many light vertices (num_lights * spl * light_depth > 2^24)");
     const int total_light_paths = s->nl * spl;
-    const int n_lv = total_light_paths * light_depth;
+    const int n_lv = (int) n_lv64;
     // slots per pass: bound the contribution table (16 B per pair) to about 1 GiB
     int spass = P.samples_per_pass;
     if(spass <= 0){
@@ -570,6 +586,9 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
     spass = std::min(spass, spp);
     size_t slots = (size_t) tl.n_local * spass;
     if(slots > 0x7FFFFFF0ull) return fail(HPT_ERR_INVALID, "too many path slots per pass");
+    if((double) slots * (double) std::max(n_lv, 1) * 16.0 > 64.0 * 1073741824.0)
+        return fail(HPT_ERR_INVALID, "contribution table (path slots x light vertices x 16 B) would exceed 64 GiB: lower spl, light_depth, "
+                                     "the image size per rank or samples_per_pass");
     const int max_iters = eye_depth + P.max_delta + 1;
     int n_counters = 2 * (max_iters + 2);
     rc = ensure_workspace(s, slots, tl.n_local, n_counters);
@@ -656,12 +675,20 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
 
 namespace {
 
-// the scene kept by the one-shot wrappers (include/hpt.h, hpt_pt_render_wrapper)
-struct WrapperCache { std::mutex mu; hpt_scene *scene = nullptr; int device = -1; } g_wrap;
+// what the one-shot wrappers keep between calls (include/hpt.h, hpt_pt_render_wrapper): the scene of the current
+// device, or -- when more than one device is configured (hpt_wrapper_set_devices / HPT_DEVICES) -- the fan-out
+struct WrapperCache { std::mutex mu; hpt_scene *scene = nullptr; int device = -1; hpt_multi *multi = nullptr; int devices = 0; } g_wrap;
 
 bool wrapper_cache_enabled(){
-    const char *e = getenv("HPT_WRAPPER_CACHE");
-    return !(e && e[0] == '0');
+    static const bool on = [](){ const char *e = getenv("HPT_WRAPPER_CACHE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// number of devices the one-shot wrappers render on: hpt_wrapper_set_devices(), else HPT_DEVICES, else 1
+int wrapper_devices(){
+    if(g_wrap.devices > 0) return g_wrap.devices;
+    static const int from_env = [](){ const char *e = getenv("HPT_DEVICES"); int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+    return from_env;
 }
 
 bool same_bytes(const std::vector<unsigned char> &kept, const void *given, size_t bytes){
@@ -694,26 +721,39 @@ void wrapper_release(hpt_scene *s){
     g_err = keep;
 }
 
-} // namespace
-
-extern "C" {
-
-const char *hpt_last_error(void){ return g_err.c_str(); }
-
-int hpt_device_count(void){
-    int n = 0;
-    if(hipGetDeviceCount(&n) != hipSuccess) return -1;
-    return n;
+// g_wrap.mu held: the kept fan-out over `devices` devices for these arrays, else a new one
+int wrapper_multi(int devices, const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt, hpt_multi **out){
+    if(g_wrap.multi && wrapper_cache_enabled() && hpt::multi_matches(g_wrap.multi, devices, lights, nl, spheres, ns, tris, nt)){
+        *out = g_wrap.multi;
+        return HPT_OK;
+    }
+    if(g_wrap.multi){ hpt_multi_destroy(g_wrap.multi); g_wrap.multi = nullptr; }
+    int rc = hpt_multi_create(lights, nl, spheres, ns, tris, nt, nullptr, devices, 0, out);
+    if(rc) return rc;
+    if(wrapper_cache_enabled()) g_wrap.multi = *out;
+    return HPT_OK;
 }
 
-int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
-                     hpt_scene **out){
-    if(!out) return fail(HPT_ERR_INVALID, "null out_scene");
+void wrapper_release_multi(hpt_multi *m){
+    if(m == g_wrap.multi) return;
+    std::string keep = g_err;
+    hpt_multi_destroy(m);
+    g_err = keep;
+}
+
+} // namespace
+
+namespace hpt {
+
+int fail_with(int code, const std::string &msg){ return fail(code, msg); }     // for hpt_multi.cpp
+
+// Uploads a flattened scene to the current device (hpt_scene_create = build_host_scene + this; the multi-device
+// fan-out builds once and uploads to every device).
+int scene_upload(const HostScene &hs, const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                 hpt_scene **out){
     *out = nullptr;
-    HostScene hs;
-    const char *err = build_host_scene(lights, nl, spheres, ns, tris, nt, hs);
-    if(err && *err) return fail(HPT_ERR_INVALID, err);
-    hpt_scene *s = new hpt_scene();
+    hpt_scene *s = new (std::nothrow) hpt_scene();
+    if(!s) return fail(HPT_ERR_NOMEM, "out of host memory");
     auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipGetDevice(&s->device);
     if(e == hipSuccess){ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount; }
@@ -726,7 +766,7 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
     if(e != hipSuccess){
         std::string msg = std::string("scene upload: ") + hipGetErrorString(e);
         hpt_scene_destroy(s);
-        return fail(HPT_ERR_DEVICE, msg);
+        return fail(e == hipErrorOutOfMemory ? HPT_ERR_NOMEM : HPT_ERR_DEVICE, msg);
     }
     e = hipMalloc((void **) &s->d_tri_frames, std::max<size_t>((size_t) nt, 1) * 4 * sizeof(float4));
     if(e == hipSuccess){
@@ -736,7 +776,7 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
     if(e != hipSuccess){
         std::string msg = std::string("triangle frames: ") + hipGetErrorString(e);
         hpt_scene_destroy(s);
-        return fail(HPT_ERR_DEVICE, msg);
+        return fail(e == hipErrorOutOfMemory ? HPT_ERR_NOMEM : HPT_ERR_DEVICE, msg);
     }
     auto t1 = std::chrono::steady_clock::now();
     s->sd.nodes = (const float4 *) s->d_nodes; s->sd.tris = (const float4 *) s->d_tris;
@@ -758,6 +798,28 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
     s->stats.ms_upload = std::chrono::duration<double, std::milli>(t1 - t0).count();
     *out = s;
     return HPT_OK;
+}
+
+} // namespace hpt
+
+extern "C" {
+
+const char *hpt_last_error(void){ return g_err.c_str(); }
+
+int hpt_device_count(void){
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                     hpt_scene **out){
+    if(!out) return fail(HPT_ERR_INVALID, "null out_scene");
+    *out = nullptr;
+    HostScene hs;
+    const char *err = build_host_scene(lights, nl, spheres, ns, tris, nt, hs);
+    if(err && *err) return fail(HPT_ERR_INVALID, err);
+    return hpt::scene_upload(hs, lights, nl, spheres, ns, tris, nt, out);
 }
 
 void hpt_scene_destroy(hpt_scene *s){
@@ -836,6 +898,15 @@ void hpt_wrapper_cache_clear(void){
     std::lock_guard<std::mutex> lock(g_wrap.mu);
     if(g_wrap.scene) hpt_scene_destroy(g_wrap.scene);
     g_wrap.scene = nullptr; g_wrap.device = -1;
+    if(g_wrap.multi) hpt_multi_destroy(g_wrap.multi);
+    g_wrap.multi = nullptr;
+}
+
+int hpt_wrapper_set_devices(int num_devices){
+    if(num_devices < 0) return fail(HPT_ERR_INVALID, "negative device count");
+    std::lock_guard<std::mutex> lock(g_wrap.mu);
+    g_wrap.devices = num_devices;
+    return HPT_OK;
 }
 
 int hpt_pt_render_wrapper(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
@@ -843,6 +914,17 @@ int hpt_pt_render_wrapper(const void *lights, int nl, const void *spheres, int n
                           int W, int H, int light_depth, int light_sample, int eye_depth, int spp, int64_t seed){
     (void) scene_min; (void) scene_max; (void) light_depth; (void) light_sample;   // ignored by the reference too
     std::lock_guard<std::mutex> lock(g_wrap.mu);
+    if(wrapper_devices() > 1){
+        // the blocking call fans out over the node's devices internally (image tiles, RCCL gather): hpt_multi.cpp
+        hpt_multi *m = nullptr;
+        int rc = wrapper_multi(wrapper_devices(), lights, nl, spheres, ns, tris, nt, &m);
+        if(rc) return rc;
+        hpt_params p; memset(&p, 0, sizeof p);
+        p.seed = seed >= 0 ? (uint64_t) seed : (uint64_t) time(nullptr);
+        rc = hpt_multi_render_pt(m, camera, W, H, eye_depth, spp, &p, host_image);
+        wrapper_release_multi(m);
+        return rc;
+    }
     hpt_scene *s = nullptr;
     int rc = wrapper_scene(lights, nl, spheres, ns, tris, nt, &s);
     if(rc) return rc;
@@ -865,17 +947,16 @@ int hpt_trace_closest(hpt_scene *s, const float *origins, const float *dirs, int
                       float *t_out, int32_t *prim_out){
     if(!s || !origins || !dirs || !t_out || !prim_out || n < 0) return fail(HPT_ERR_INVALID, "bad argument");
     if(n == 0) return HPT_OK;
-    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr; int32_t *d_p = nullptr;
+    DevBuf d_o, d_d, d_t, d_p;
     size_t b3 = (size_t) n * 3 * sizeof(float);
-    HIP_TRY(hipMalloc((void **) &d_o, b3)); HIP_TRY(hipMalloc((void **) &d_d, b3));
-    HIP_TRY(hipMalloc((void **) &d_t, (size_t) n * 4)); HIP_TRY(hipMalloc((void **) &d_p, (size_t) n * 4));
-    HIP_TRY(hipMemcpy(d_o, origins, b3, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_d, dirs, b3, hipMemcpyHostToDevice));
-    launch_probe_closest(nullptr, s->sd, d_o, d_d, n, (flags & HPT_FLAG_BRUTE_FORCE) ? 1 : 0, d_t, d_p);
+    HIP_TRY(d_o.alloc(b3)); HIP_TRY(d_d.alloc(b3));
+    HIP_TRY(d_t.alloc((size_t) n * 4)); HIP_TRY(d_p.alloc((size_t) n * 4));
+    HIP_TRY(hipMemcpy(d_o.p, origins, b3, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d.p, dirs, b3, hipMemcpyHostToDevice));
+    launch_probe_closest(nullptr, s->sd, d_o.as<float>(), d_d.as<float>(), n, (flags & HPT_FLAG_BRUTE_FORCE) ? 1 : 0, d_t.as<float>(), d_p.as<int32_t>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(t_out, d_t, (size_t) n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(prim_out, d_p, (size_t) n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_p);
+    HIP_TRY(hipMemcpy(t_out, d_t.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(prim_out, d_p.p, (size_t) n * 4, hipMemcpyDeviceToHost));
     return HPT_OK;
 }
 
@@ -933,6 +1014,16 @@ int hpt_bdpt_render_wrapper(const void *lights, int nl, const void *spheres, int
         for(int c = 0; c < 3; ++c) illum[c] = illum[c] * (float) light_sample;
     }
     std::lock_guard<std::mutex> lock(g_wrap.mu);
+    if(wrapper_devices() > 1){
+        hpt_multi *m = nullptr;
+        int rc = wrapper_multi(wrapper_devices(), L.data(), nl, spheres, ns, tris, nt, &m);
+        if(rc) return rc;
+        hpt_params p; memset(&p, 0, sizeof p);
+        p.seed = seed >= 0 ? (uint64_t) seed : (uint64_t) time(nullptr);
+        rc = hpt_multi_render_bdpt(m, camera, W, H, eye_depth, light_depth, spp, spl, &p, host_image);
+        wrapper_release_multi(m);
+        return rc;
+    }
     hpt_scene *s = nullptr;
     int rc = wrapper_scene(L.data(), nl, spheres, ns, tris, nt, &s);
     if(rc) return rc;
@@ -946,16 +1037,15 @@ int hpt_bdpt_render_wrapper(const void *lights, int nl, const void *spheres, int
 int hpt_trace_visibility(hpt_scene *s, const float *p1, const float *p2, int n, int flags, int32_t *vis_out){
     if(!s || !p1 || !p2 || !vis_out || n < 0) return fail(HPT_ERR_INVALID, "bad argument");
     if(n == 0) return HPT_OK;
-    float *d_a = nullptr, *d_b = nullptr; int32_t *d_v = nullptr;
+    DevBuf d_a, d_b, d_v;
     size_t b3 = (size_t) n * 3 * sizeof(float);
-    HIP_TRY(hipMalloc((void **) &d_a, b3)); HIP_TRY(hipMalloc((void **) &d_b, b3));
-    HIP_TRY(hipMalloc((void **) &d_v, (size_t) n * 4));
-    HIP_TRY(hipMemcpy(d_a, p1, b3, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_b, p2, b3, hipMemcpyHostToDevice));
-    launch_probe_visibility(nullptr, s->sd, d_a, d_b, n, (flags & HPT_FLAG_BRUTE_FORCE) ? 1 : 0, d_v);
+    HIP_TRY(d_a.alloc(b3)); HIP_TRY(d_b.alloc(b3));
+    HIP_TRY(d_v.alloc((size_t) n * 4));
+    HIP_TRY(hipMemcpy(d_a.p, p1, b3, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b.p, p2, b3, hipMemcpyHostToDevice));
+    launch_probe_visibility(nullptr, s->sd, d_a.as<float>(), d_b.as<float>(), n, (flags & HPT_FLAG_BRUTE_FORCE) ? 1 : 0, d_v.as<int32_t>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(vis_out, d_v, (size_t) n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_a); hipFree(d_b); hipFree(d_v);
+    HIP_TRY(hipMemcpy(vis_out, d_v.p, (size_t) n * 4, hipMemcpyDeviceToHost));
     return HPT_OK;
 }
 

@@ -119,3 +119,10 @@ const char *build_host_scene(const void *lights, int nl, const void *spheres, in
                              const void *tris, int nt, HostScene &out);
 
 } // namespace hpt
+
+struct hpt_scene;
+namespace hpt {
+// uploads a flattened scene to the current HIP device (hpt_api.cpp); the records are kept for the bidirectional path
+int scene_upload(const HostScene &hs, const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                 hpt_scene **out);
+} // namespace hpt

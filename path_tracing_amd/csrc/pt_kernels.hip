@@ -1034,13 +1034,7 @@ void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBu
     int stack_words = (stack_levels + 1) * kBlock;
     // every ray of this launch is a long one: lanes refill sooner, a workgroup takes more rays (a lane
     // gets ~8 rays, which evens out their lengths) and the leaf phase waits for fewer stragglers
-    uint32_t chunk2 = kLongChunk; int refill2 = kLongRefillMin, node_min2 = kLongNodeMin;
-    if(const char *e = getenv("HPT_TUNE_LONG")){           // development: chunk/256 << 16 | refill << 8 | node_min
-        long v = strtol(e, nullptr, 0);
-        if((v >> 16) & 0xFF) chunk2 = (uint32_t) ((v >> 16) & 0xFF) * 256u;
-        if((v >> 8) & 0xFF) refill2 = (int) ((v >> 8) & 0xFF);
-        if(v & 0xFF) node_min2 = (int) (v & 0xFF);
-    }
+    const uint32_t chunk2 = kLongChunk; const int refill2 = kLongRefillMin, node_min2 = kLongNodeMin;
     uint32_t per = (max_items + kBlock - 1) / kBlock;
     uint64_t g = (uint64_t) per * ((extend ? 1u : 0u) + (shadow ? 1u : 0u));
     uint32_t g2 = g < 8192u ? (uint32_t) (g < 1u ? 1u : g) : 8192u;

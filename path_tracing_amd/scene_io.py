@@ -452,3 +452,24 @@ def scene_to_text(lights, spheres, tris, W, H, eye=CORNELL_EYE, look=CORNELL_LOO
             L["pos"][0], L["pos"][1], L["pos"][2], L["dir"][0], L["dir"][1], L["dir"][2],
             L["illum"][0], L["illum"][1], L["illum"][2], deg, int(L["is_parallel"]), L["light_ball"]["r"]))
     return "\n".join(out) + "\n"
+
+
+def object_order(scene_desc=None, spheres=None, tris=None):
+    """(kind, index, group) arrays: the scene file's insertion order per group when a parsed
+    SceneDesc is given, otherwise spheres then triangles in one group."""
+    kind, index, group = [], [], []
+    if scene_desc is not None:
+        ns = nt = 0
+        for gid in sorted(scene_desc.groups):
+            for obj in scene_desc.groups[gid]:
+                if obj[0] == "S":
+                    kind.append(0); index.append(ns); ns += 1
+                else:
+                    kind.append(1); index.append(nt); nt += 1
+                group.append(gid)
+    else:
+        for i in range(len(spheres)):
+            kind.append(0); index.append(i); group.append(0)
+        for i in range(len(tris)):
+            kind.append(1); index.append(i); group.append(0)
+    return (np.asarray(kind, np.int32), np.asarray(index, np.int32), np.asarray(group, np.int32))

@@ -4,7 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import path_tracing_amd as hpt
 from path_tracing_amd import scene_io as S
-import oracle
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 def timed(fn, reps=3):
@@ -14,7 +13,7 @@ def timed(fn, reps=3):
     return float(np.median(ms[1:]))
 # config 1: cpu_bdpt estimator on input.txt, 256x256, 4 spp
 sc = S.load_scene(os.path.join(here, "tests/golden/scenes/input.txt"))
-L, sp, tr = S.flatten_for_pt(sc); order = oracle.object_order(sc)
+L, sp, tr = S.flatten_for_pt(sc); order = S.object_order(sc)
 cam = S.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, 256, 256, tan_in_float=True)
 scene = hpt.Scene(L, sp, tr); scene.set_groups(*order)
 ms = timed(lambda: scene.render_bdpt(cam, 256, 256, 4, 4, 4, 8, hpt.make_params(seed=1)))
@@ -29,7 +28,7 @@ out["cfg2_pt_cornell_diffuse_512x512_64spp"] = {"ms": ms, "Msamples_per_s": 512 
 scene.close()
 # config 4: BDPT on mis_test.txt, 1024x1024, 64 spp
 sc4 = S.load_scene(os.path.join(here, "tests/golden/scenes/mis_test.txt"))
-L4, sp4, tr4 = S.flatten_for_pt(sc4); order4 = oracle.object_order(sc4)
+L4, sp4, tr4 = S.flatten_for_pt(sc4); order4 = S.object_order(sc4)
 cam4 = S.make_camera(sc4.eye, sc4.look_at, sc4.view_up, sc4.fov, 1024, 1024, tan_in_float=True)
 scene = hpt.Scene(L4, sp4, tr4); scene.set_groups(*order4)
 ms = timed(lambda: scene.render_bdpt(cam4, 1024, 1024, 4, 4, 64, 8, hpt.make_params(seed=1)), reps=2)

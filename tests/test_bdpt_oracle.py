@@ -13,7 +13,7 @@ def _input(sio, oracle_mod, raw_light_dirs):
     if raw_light_dirs:                       # run_cpu_bdpt receives the lights as parsed (src/main_cli.cpp:131-140)
         for i, l in enumerate(sc.lights):
             L[i]["dir"] = l["dir"]
-    return sc, L, sp, tr, oracle_mod.object_order(sc)
+    return sc, L, sp, tr, sio.object_order(sc)
 
 
 def test_advisory_replay_of_survey_cpu_bdpt_image(oracle_mod, sio):

@@ -1,0 +1,178 @@
+"""GPU tests of the multi-device path and of the two largest BASELINE.json configurations.
+
+* the single-process fan-out behind the blocking call (include/hpt.h, hpt_multi_*): several ranks on the one
+  GPU of the test box with peer copies, and the RCCL exchange with the one rank RCCL accepts there;
+* torch.distributed's RCCL gather with a one-rank communicator (the collective bench.py runs at every N);
+* configs[4] (1M triangles, 4096 x 4096, image tiled over 8 ranks) at reduced spp: 8 virtual ranks == 1 rank
+  bit for bit, an oracle window over the sphere's silhouette, traversal-cost properties;
+* configs[2] at its full shape (100k triangles, 1024 x 1024, 256 spp = four passes on two pipelines).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _cornell(sio, n, W, H):
+    L, sp, tr = sio.cornell_with_sphere(n)
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, W, H)
+    return L, sp, tr, cam
+
+
+def test_fan_out_over_virtual_ranks_matches_one_device(hpt, sio):
+    L, sp, tr, cam = _cornell(sio, 5000, 200, 136)
+    with hpt.Scene(L, sp, tr) as scene:
+        ref = scene.render_pt(cam, 200, 136, 4, 6, hpt.make_params(seed=31))
+    for ranks in (2, 3, 5):
+        with hpt.MultiScene(L, sp, tr, device_ids=[0] * ranks, exchange=1) as multi:
+            assert multi.num_devices == ranks
+            img = multi.render_pt(cam, 200, 136, 4, 6, hpt.make_params(seed=31))
+            t = multi.timing()
+        assert np.array_equal(img, ref), "ranks=%d" % ranks
+        assert len(t["render_ms_per_device"]) == ranks and min(t["render_ms_per_device"]) > 0 and t["total_ms"] > 0
+
+
+def test_fan_out_rccl_exchange_with_the_visible_devices(hpt, sio, input_scene, oracle_mod):
+    """exchange = 0: ncclCommInitAll over every visible device (one on the test box) and one ncclGather per device."""
+    sc, (L, sp, tr) = input_scene
+    W, H = 96, 64
+    cam = sio.camera_for(sc, W, H)
+    ref, _ = oracle_mod.pt_render(L, sp, tr, cam, W, H, 4, 3, seed=8)
+    with hpt.MultiScene(L, sp, tr, num_devices=0, exchange=0) as multi:
+        assert multi.num_devices == hpt.device_count()
+        img = multi.render_pt(cam, W, H, 4, 3, hpt.make_params(seed=8))
+        assert multi.timing()["gather_ms"] >= 0.0
+    assert_parity(img, ref)
+    # RCCL refuses two ranks on one device: reported as an error, not substituted
+    with pytest.raises(hpt.HptError):
+        hpt.MultiScene(L, sp, tr, device_ids=[0, 0], exchange=0)
+
+
+def test_fan_out_bdpt_and_wrapper_device_count(hpt, sio, oracle_mod):
+    sc = sio.load_scene(os.path.join(os.path.dirname(__file__), "golden", "scenes", "input.txt"))
+    L, sp, tr = sio.flatten_for_pt(sc)
+    order = sio.object_order(sc)
+    W, H = 48, 40
+    cam = sio.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, W, H, tan_in_float=True)
+    with hpt.Scene(L, sp, tr) as scene:
+        scene.set_groups(*order)
+        ref = scene.render_bdpt(cam, W, H, 4, 4, 2, 4, hpt.make_params(seed=4))
+    with hpt.MultiScene(L, sp, tr, device_ids=[0, 0, 0], exchange=1) as multi:
+        multi.set_groups(*order)
+        img = multi.render_bdpt(cam, W, H, 4, 4, 2, 4, hpt.make_params(seed=4))
+    assert np.array_equal(img, ref)
+    # the one-shot wrapper fans out over hpt_wrapper_set_devices() devices: all visible ones work, one more is an error
+    n = hpt.device_count()
+    try:
+        hpt.wrapper_set_devices(n)
+        a = hpt.pt_render_wrapper(L, sp, tr, sio.camera_for(sc, W, H), W, H, 4, 2, seed=12)
+        hpt.wrapper_set_devices(1)
+        b = hpt.pt_render_wrapper(L, sp, tr, sio.camera_for(sc, W, H), W, H, 4, 2, seed=12)
+        assert np.array_equal(a, b)
+        hpt.wrapper_set_devices(n + 1)
+        with pytest.raises(hpt.HptError):
+            hpt.pt_render_wrapper(L, sp, tr, sio.camera_for(sc, W, H), W, H, 4, 2, seed=12)
+    finally:
+        hpt.wrapper_set_devices(0)
+        hpt.wrapper_cache_clear()
+
+
+def test_rccl_gather_through_a_one_rank_communicator(hpt, sio, input_scene):
+    """The exchange step of the one-process-per-GPU path (path_tracing_amd/distributed.py) through RCCL itself:
+    backend "nccl", world 1 -- the gather bench.py runs inside its timed region at every N."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from path_tracing_amd import distributed
+    sc, (L, sp, tr) = input_scene
+    W, H = 80, 56
+    cam = sio.camera_for(sc, W, H)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        stream = torch.cuda.current_stream().cuda_stream
+        with hpt.Scene(L, sp, tr) as scene:
+            ref = scene.render_pt(cam, W, H, 4, 3, hpt.make_params(seed=3))
+            n_local = hpt.local_pixels(W, H, hpt.make_params())
+            local = torch.zeros((n_local, 3), dtype=torch.float32, device="cuda")
+            image = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+            seen = []
+
+            def render_local():
+                scene.render_pt_device(cam, W, H, 4, 3, hpt.make_params(seed=3), local.data_ptr(), stream)
+                return local
+
+            def untile(g):
+                seen.append(tuple(g.shape))
+                hpt.untile(g.data_ptr(), image.data_ptr(), W, H, hpt.make_params(), stream)
+                return image
+
+            out = distributed.render_tiled(render_local, untile, 0, 1, always_collective=True)
+            torch.cuda.synchronize()
+            assert seen == [(1, n_local, 3)]
+            assert np.array_equal(out.cpu().numpy(), ref)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_shape_one_million_triangles_4096(hpt, sio, oracle_mod):
+    """configs[4]: 1M-triangle scene, 4096 x 4096, image tiled over 8 ranks -- at 2 spp instead of 1024."""
+    import torch
+    W = H = 4096
+    spp = 2
+    L, sp, tr, cam = _cornell(sio, 1_000_000, W, H)
+    assert 990_000 < len(tr) < 1_010_000
+    with hpt.Scene(L, sp, tr) as scene:
+        st0 = scene.stats()
+        a = scene.render_pt(cam, W, H, 4, spp, hpt.make_params(seed=1, flags=hpt.FLAG_COUNT_WORK))
+        st = scene.stats()
+        stream = torch.cuda.current_stream().cuda_stream
+        world = 8
+        n_local = hpt.local_pixels(W, H, hpt.make_params(world=world))
+        assert n_local == W * H // world
+        gathered = torch.zeros((world, n_local, 3), dtype=torch.float32, device="cuda")
+        for r in range(world):
+            scene.render_pt_device(cam, W, H, 4, spp, hpt.make_params(seed=1, rank=r, world=world), gathered[r].data_ptr(), stream)
+        image = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        hpt.untile(gathered.data_ptr(), image.data_ptr(), W, H, hpt.make_params(world=world), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(image.cpu().numpy(), a)                  # 8 virtual ranks == 1 rank, bit for bit
+        del gathered, image
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.mean() > 0.05
+    assert st["samples"] == W * H * spp
+    # traversal cost: a balanced tree over N triangles is log2(N / leaf size) deep; the builder's depth and the boxes a
+    # ray tests stay within small multiples of that (SURVEY 8d sanity gate: nodes per ray <= 3 log2 N)
+    assert st0["bvh_depth"] <= 2 * int(np.ceil(np.log2(len(tr))))
+    rays = st["closest_rays"] + st["shadow_rays"]
+    assert (st["boxes_closest"] + st["boxes_shadow"]) / 2 / rays < 3 * np.log2(len(tr))
+    assert 3.0 < st["closest_rays"] / st["samples"] < 5.5
+    # the oracle (brute force over the million triangles) on a 16 x 12 window across the sphere's silhouette
+    x0, y0, x1, y1 = 2240, 1520, 2256, 1532
+    ref, _ = oracle_mod.pt_render(L, sp, tr, cam, W, H, 4, spp, seed=1, window=(x0, y0, x1, y1))
+    assert ref[y0:y1, x0:x1].max() > 0
+    assert_parity(a[y0:y1, x0:x1], ref[y0:y1, x0:x1])
+
+
+def test_config3_full_shape_256spp(hpt, sio, oracle_mod):
+    """configs[2] as benchmarked: ~100k triangles, 1024 x 1024, 256 spp (four 64-spp passes, two in flight)."""
+    W = H = 1024
+    L, sp, tr, cam = _cornell(sio, 100_000, W, H)
+    with hpt.Scene(L, sp, tr) as scene:
+        full = scene.render_pt(cam, W, H, 4, 256, hpt.make_params(seed=1))
+        single = scene.render_pt(cam, W, H, 4, 256, hpt.make_params(seed=1, flags=hpt.FLAG_SINGLE_PIPELINE))
+        assert np.array_equal(full, single)
+        # progressive: the 256-spp sum is the ordered sum of four 64-spp slices only in exact arithmetic, so compare
+        # a slice instead: samples [64, 128) rendered alone == the same slice inside a 2-pass render of [64, 192)
+        s1 = scene.render_pt(cam, W, H, 4, 64, hpt.make_params(seed=1, sample_offset=64, flags=hpt.FLAG_OUTPUT_SUM))
+        s2 = scene.render_pt(cam, W, H, 4, 64, hpt.make_params(seed=1, sample_offset=64, flags=hpt.FLAG_OUTPUT_SUM, samples_per_pass=16))
+        assert np.array_equal(s1, s2)
+    # all 256 samples of an 8 x 8 window on the sphere's silhouette against the oracle
+    x0, y0, x1, y1 = 568, 384, 576, 392
+    ref, _ = oracle_mod.pt_render(L, sp, tr, cam, W, H, 4, 256, seed=1, window=(x0, y0, x1, y1))
+    assert_parity(full[y0:y1, x0:x1], ref[y0:y1, x0:x1])

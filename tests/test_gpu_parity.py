@@ -280,7 +280,7 @@ def test_reference_named_cpp_entry_point(hpt, sio, input_scene, oracle_mod, monk
 def _bdpt_case(sio, oracle_mod, name):
     sc = sio.load_scene(os.path.join(GOLDEN, "scenes", name + ".txt"))
     L, sp, tr = sio.flatten_for_pt(sc)
-    return sc, L, sp, tr, oracle_mod.object_order(sc)
+    return sc, L, sp, tr, sio.object_order(sc)
 
 
 @pytest.mark.parametrize("name,W,H,spp,spl,depth", [
@@ -317,7 +317,7 @@ def test_bdpt_synthetic_scene_and_ties(hpt, sio, oracle_mod):
     L, sp, tr = sio.cornell_with_sphere(1500)
     dup = tr[:12].copy(); dup["mtl"]["base_color"] = (0.1, 0.8, 0.1)
     tr = np.concatenate([tr, dup])
-    order = oracle_mod.object_order(None, sp, tr)
+    order = sio.object_order(None, sp, tr)
     ref, _ = oracle_mod.bdpt_render(L, sp, tr, order, sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 48, 48, 4, 4, 2, 4, seed=3)
     cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 48, 48, tan_in_float=True)
     with hpt.Scene(L, sp, tr) as scene:
@@ -340,7 +340,7 @@ def test_bdpt_no_lights_and_one_shot_wrapper(hpt, sio, oracle_mod):
                                      tr.ctypes.data_as(C.c_void_p), len(tr), z3, z3, np.ascontiguousarray(cam).ctypes.data_as(C.c_void_p),
                                      img.ctypes.data_as(C.c_void_p), 24, 24, 4, 8, 4, 2, 8, C.c_int64(6))
     assert rc == 0
-    ref, _ = oracle_mod.bdpt_render(L, sp, tr, oracle_mod.object_order(None, sp, tr), sc.eye, sc.look_at, sc.view_up, sc.fov, 24, 24, 4, 4, 2, 8, seed=6)
+    ref, _ = oracle_mod.bdpt_render(L, sp, tr, sio.object_order(None, sp, tr), sc.eye, sc.look_at, sc.view_up, sc.fov, 24, 24, 4, 4, 2, 8, seed=6)
     assert_parity(img, ref)
 
 
@@ -467,7 +467,7 @@ def test_bdpt_virtual_ranks_assemble_bitwise(hpt, sio, oracle_mod):
     import torch
     sc = sio.load_scene(os.path.join(GOLDEN, "scenes", "input.txt"))
     L, sp, tr = sio.flatten_for_pt(sc)
-    order = oracle_mod.object_order(sc)
+    order = sio.object_order(sc)
     W, H, spp, spl = 52, 40, 2, 4
     cam = sio.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, W, H, tan_in_float=True)
     stream = torch.cuda.current_stream().cuda_stream

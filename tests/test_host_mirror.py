@@ -132,7 +132,7 @@ def test_cli_bdpt_mode_matches_the_cpu_bdpt_oracle(tmp_path, sio, oracle_mod):
     img = np.frombuffer(blob[len(head):], np.float32).reshape(32, 40, 3)[::-1]
     sc = sio.load_scene(scene)
     L, sp, tr = sio.flatten_for_pt(sc)
-    order = oracle_mod.object_order(sc)
+    order = sio.object_order(sc)
     # the oracle derives its camera from (eye, look_at, up, fov) with a float tangent; the CLI's init_camera takes the
     # tangent in double, so compare through the GPU library with the CLI's own camera instead of the oracle's
     import path_tracing_amd as hpt

@@ -61,3 +61,51 @@ def test_gather_and_untile_over_gloo(tmp_path, oracle_mod, sio, world, W, H, til
     L, sp, tr = sio.flatten_for_pt(sc)
     ref, _ = oracle_mod.pt_render(L, sp, tr, sio.camera_for(sc, W, H), W, H, 4, 2, seed=13)
     assert np.array_equal(got, ref)
+
+
+def test_one_rank_gather_goes_through_the_backend_when_asked(tmp_path):
+    """always_collective: the world-1 gather runs through the process group (bench.py does this with RCCL
+    so that the collective is exercised at N = 1); without a group, or without the flag, it is a view."""
+    from path_tracing_amd import distributed
+    local = torch.arange(24, dtype=torch.float32).reshape(8, 3)
+    assert distributed.gather_framebuffer(local, 0, 1).data_ptr() == local.data_ptr()
+    assert distributed.gather_framebuffer(local, 0, 1, always_collective=True).data_ptr() == local.data_ptr()   # no group yet
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        calls = []
+        out = distributed.render_tiled(lambda: local, lambda g: g.clone(), 0, 1, always_collective=True, on_gather=calls.append)
+        assert calls == ["begin", "end"]
+        assert out.shape == (1, 8, 3) and torch.equal(out[0], local)
+        g = distributed.gather_framebuffer(local, 0, 1, always_collective=True)
+        assert g.data_ptr() != local.data_ptr() and torch.equal(g[0], local)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_starts_its_own_ranks_as_a_child_process(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: torch.distributed.run is started as a CHILD (subprocess),
+    before anything imports torch.cuda, with the rendezvous on 127.0.0.1; under a launcher (RANK set) it is a rank."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"] = cmd; seen["env"] = env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("RANK", raising=False); monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                   # the child's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and os.path.basename(cmd[-5]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
