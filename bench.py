@@ -119,6 +119,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))        # nothing has touched the GPU yet
 
+    # ONE line on stdout: native libraries write there too (RCCL prints a version banner when NCCL_DEBUG=VERSION is in
+    # the environment, as on the GPU boxes), so file descriptor 1 is pointed at stderr for the run and the JSON line
+    # goes to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import path_tracing_amd as hpt
@@ -356,7 +363,8 @@ def main():
                                        "max_abs": float(np.abs(d).max()), "bit_identical": bool(np.array_equal(got, ref_win)),
                                        "oracle": "oracle/pt_oracle.cpp (brute-force scans), the pt_port render timed above"}
         out["verify"] = verify
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     scene.close()
     if dist.is_initialized():
         dist.barrier()

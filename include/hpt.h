@@ -211,6 +211,20 @@ int hpt_multi_render_bdpt(hpt_multi *multi, const void *camera, int W, int H, in
 int hpt_multi_get_timing(const hpt_multi *multi, double *render_ms_per_device, double *gather_ms, double *total_ms);
 int hpt_wrapper_set_devices(int num_devices);
 
+/* ---- 8-bit output stage on the device -------------------------------------------------------------
+ * Replaces the per-pixel loop of the reference CLI, src/main_cli.cpp:225-242: per channel clamp to [0, 1],
+ * pow(x, 1/2.2), x 255, truncate.  The device looks the byte up in a table of 255 thresholds that the host
+ * computes with its own powf, so the bytes are exactly those of the host loop (hpt_tonemap_reference runs
+ * that loop; hpt_tonemap_table returns thresholds[k] = the smallest float whose byte is >= k, [0] = -inf).
+ *   d_linear_rgb  3 floats per pixel (the image hpt_untile / hpt_render_* produce), device memory
+ *   d_rgb8        3 bytes per pixel, device memory, 4-byte aligned
+ *   bgr           non-zero: the reference's cv::Vec3b order (B, G, R); zero: R, G, B
+ * hpt_tonemap_host takes and returns host buffers (upload, kernel, download). */
+int hpt_tonemap(const void *d_linear_rgb, void *d_rgb8, int64_t num_pixels, int bgr, void *hip_stream);
+int hpt_tonemap_host(const float *linear_rgb, unsigned char *rgb8, int64_t num_pixels, int bgr);
+void hpt_tonemap_table(float thresholds_out[256]);
+void hpt_tonemap_reference(const float *linear_rgb, unsigned char *rgb8, int64_t num_pixels, int bgr);
+
 /* Ray-level probes of the intersection kernels (tests): n rays, origins/directions as
  * packed float3.  prim is the reference scan ordinal (spheres, then light balls, then
  * triangles in input order), -1 on a miss; t is 1e20f on a miss. */

@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -92,7 +93,7 @@ struct hpt_scene {
         uint32_t *queue[2] = { nullptr, nullptr }, *squeue = nullptr, *lqueue[2] = { nullptr, nullptr };
         uint32_t *counters = nullptr; int n_counters = 0;
         uint32_t *h_count = nullptr;
-        hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+        hipStream_t stream = nullptr; int priority = 0; hipEvent_t ev_fork = nullptr, ev_done = nullptr;
     } p2;
     const uint32_t *last_counters = nullptr;     // counters of the last pass rendered (either pipeline)
     uint32_t *counters = nullptr; int n_counters = 0;
@@ -139,7 +140,7 @@ void free_pipe2(hpt_scene *s){
     w.pb = PathBuf{}; w.sb = ShadowBuf{}; w.queue[0] = w.queue[1] = w.squeue = w.lqueue[0] = w.lqueue[1] = nullptr; w.cap_paths = 0;
 }
 
-int ensure_pipe2(hpt_scene *s, size_t paths, int n_counters){
+int ensure_pipe2(hpt_scene *s, size_t paths, int n_counters, hipStream_t caller){
     hpt_scene::Pipe2 &w = s->p2;
     if(paths > w.cap_paths){
         free_pipe2(s);
@@ -165,7 +166,21 @@ int ensure_pipe2(hpt_scene *s, size_t paths, int n_counters){
         w.n_counters = n_counters;
     }
     if(!w.h_count) HIP_TRY(hipHostMalloc((void **) &w.h_count, 64));
-    if(!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    // The two pipelines only overlap if their streams sit on different hardware queues.  The runtime maps streams
+    // of one priority onto a small pool of queues (GPU_MAX_HW_QUEUES, 4 by default) by reference count, so once a
+    // process holds a few more streams -- RCCL's, after a communicator exists -- a second stream of the caller's
+    // priority can land on the caller's queue and the passes serialise (measured: 169 ms per config-3 render
+    // instead of 161).  Streams of another priority come from another pool: the second pipeline takes the highest
+    // priority unless the caller's stream already has it, then the default one.
+    int pr_least = 0, pr_greatest = 0, pr_caller = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+    if(hipStreamGetPriority(caller, &pr_caller) != hipSuccess){ (void) hipGetLastError(); pr_caller = 0; }
+    const int want = (pr_caller == pr_greatest && pr_greatest != 0) ? 0 : pr_greatest;
+    if(w.stream && w.priority != want){ hipStreamSynchronize(w.stream); hipStreamDestroy(w.stream); w.stream = nullptr; }
+    if(!w.stream){
+        HIP_TRY(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, want));
+        w.priority = want;
+    }
     if(!w.ev_fork){
         HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
@@ -290,7 +305,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     rc = ensure_workspace(s, paths, tl.n_local, n_counters);
     if(rc) return rc;
     if(dual){
-        rc = ensure_pipe2(s, paths, n_counters);
+        rc = ensure_pipe2(s, paths, n_counters, stream);
         if(rc) return rc;
     }
 
@@ -933,6 +948,89 @@ int hpt_pt_render_wrapper(const void *lights, int nl, const void *spheres, int n
     rc = hpt_render_pt(s, camera, W, H, eye_depth, spp, &p, host_image);
     wrapper_release(s);
     return rc;
+}
+
+// ---- 8-bit output stage ------------------------------------------------------------------------------------------
+namespace {
+
+// what the reference's host loop computes per channel (src/main_cli.cpp:233-241)
+unsigned char tonemap_byte(float x){
+    float c = std::max(0.0f, std::min(x, 1.0f));
+    float g = std::pow(c, 1.0f / 2.2f);
+    return (unsigned char) (g * 255.0f);
+}
+
+// thr[k], k = 1..255: the smallest float in [0, 1] whose byte is >= k (byte(x) is non-decreasing in x, so a binary
+// search over the bit patterns of the non-negative floats finds it); thr[0] = -inf
+const float *tonemap_thresholds(){
+    static float table[256];
+    static std::once_flag once;
+    std::call_once(once, [](){
+        table[0] = -INFINITY;
+        for(int k = 1; k < 256; ++k){
+            uint32_t lo = 0u, hi = 0x3F800000u;               // bits of 0.0f .. 1.0f; byte(1.0f) = 255 >= k
+            while(lo < hi){
+                uint32_t mid = lo + (hi - lo) / 2u;
+                float x; memcpy(&x, &mid, 4);
+                if((int) tonemap_byte(x) >= k) hi = mid; else lo = mid + 1u;
+            }
+            memcpy(&table[k], &lo, 4);
+        }
+    });
+    return table;
+}
+
+struct TonemapDevice { std::mutex mu; float *d_table[64] = {}; } g_tonemap;
+
+// the threshold table on the current device (uploaded once per device)
+int tonemap_device_table(const float **out){
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if(dev < 0 || dev >= 64) return fail(HPT_ERR_INVALID, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_tonemap.mu);
+    if(!g_tonemap.d_table[dev]){
+        float *d = nullptr;
+        HIP_TRY(hipMalloc((void **) &d, 256 * sizeof(float)));
+        hipError_t e = hipMemcpy(d, tonemap_thresholds(), 256 * sizeof(float), hipMemcpyHostToDevice);
+        if(e != hipSuccess){ hipFree(d); return fail(HPT_ERR_DEVICE, std::string("tonemap table upload: ") + hipGetErrorString(e)); }
+        g_tonemap.d_table[dev] = d;
+    }
+    *out = g_tonemap.d_table[dev];
+    return HPT_OK;
+}
+
+} // namespace
+
+void hpt_tonemap_table(float thresholds_out[256]){ memcpy(thresholds_out, tonemap_thresholds(), 256 * sizeof(float)); }
+
+void hpt_tonemap_reference(const float *linear_rgb, unsigned char *rgb8, int64_t num_pixels, int bgr){
+    for(int64_t p = 0; p < num_pixels; ++p)
+        for(int c = 0; c < 3; ++c) rgb8[p * 3 + c] = tonemap_byte(linear_rgb[p * 3 + (bgr ? 2 - c : c)]);
+}
+
+int hpt_tonemap(const void *d_linear_rgb, void *d_rgb8, int64_t num_pixels, int bgr, void *hip_stream){
+    if(num_pixels < 0 || (num_pixels > 0 && (!d_linear_rgb || !d_rgb8))) return fail(HPT_ERR_INVALID, "bad tonemap argument");
+    if(((uintptr_t) d_rgb8 & 3u) != 0u) return fail(HPT_ERR_INVALID, "tonemap output must be 4-byte aligned");
+    const float *table = nullptr;
+    int rc = tonemap_device_table(&table);
+    if(rc) return rc;
+    launch_tonemap((hipStream_t) hip_stream, (const float *) d_linear_rgb, d_rgb8, (unsigned long long) num_pixels * 3ull, bgr ? 1 : 0, table);
+    HIP_TRY(hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_tonemap_host(const float *linear_rgb, unsigned char *rgb8, int64_t num_pixels, int bgr){
+    if(num_pixels < 0 || (num_pixels > 0 && (!linear_rgb || !rgb8))) return fail(HPT_ERR_INVALID, "bad tonemap argument");
+    if(num_pixels == 0) return HPT_OK;
+    DevBuf d_in, d_out;
+    size_t n = (size_t) num_pixels * 3;
+    HIP_TRY(d_in.alloc(n * sizeof(float)));
+    HIP_TRY(d_out.alloc((n + 3) / 4 * 4));
+    HIP_TRY(hipMemcpy(d_in.p, linear_rgb, n * sizeof(float), hipMemcpyHostToDevice));
+    int rc = hpt_tonemap(d_in.p, d_out.p, num_pixels, bgr, nullptr);
+    if(rc) return rc;
+    HIP_TRY(hipMemcpy(rgb8, d_out.p, n, hipMemcpyDeviceToHost));
+    return HPT_OK;
 }
 
 int hpt_get_stats(const hpt_scene *scene, hpt_stats *out){

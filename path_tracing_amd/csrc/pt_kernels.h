@@ -88,6 +88,9 @@ void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, 
 void launch_finalize(hipStream_t s, const Tiling &tl, const float4 *accum, float *d_local, float scale);
 void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, float *d_image);
 
+// 8-bit output stage: num_values = 3 * pixels floats in, as many bytes out (d_bytes 4-byte aligned); d_thresholds: 256 floats
+void launch_tonemap(hipStream_t s, const float *d_linear, void *d_bytes, unsigned long long num_values, int bgr, const float *d_thresholds);
+
 // ray-level probes (tests)
 void launch_probe_closest(hipStream_t s, const SceneDev &sc, const float *org, const float *dir, int n, int flags,
                           float *t_out, int32_t *prim_out);

@@ -630,6 +630,39 @@ void k_untile(Tiling tl, const float *gathered, float *image){
     image[dst + 2] = gathered[src + 2];
 }
 
+// 8-bit output stage of the reference CLI (src/main_cli.cpp:227-242): per channel clamp to [0, 1], pow(x, 1/2.2),
+// x 255, truncate.  byte(x) is a non-decreasing step function of x, so the device does not evaluate powf at all:
+// thr[k] (k = 1..255) is the smallest float whose byte is >= k, found on the HOST with the host's own powf
+// (hpt_api.cpp, tonemap_thresholds), and the byte is the number of thresholds <= x -- eight steps of a binary
+// search in LDS.  The bytes are therefore exactly what the reference's host loop produces with the same libm;
+// NaN compares false everywhere and lands on 0, which is where std::max(0.0f, std::min(NaN, 1.0f)) sends it.
+// One thread packs four consecutive output bytes; bgr = 1 writes the reference's cv::Vec3b channel order.
+__global__ __launch_bounds__(kBlock)
+void k_tonemap(const float *linear, uint32_t *out_words, unsigned long long num_values, int bgr, const float *thr_table){
+    __shared__ float s_thr[256];
+    s_thr[threadIdx.x] = thr_table[threadIdx.x];
+    __syncthreads();
+    unsigned long long w = (unsigned long long) blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long first = w * 4ull;
+    if(first >= num_values) return;
+    uint32_t packed = 0u;
+    for(int k = 0; k < 4; ++k){
+        unsigned long long j = first + (unsigned long long) k;
+        if(j >= num_values) break;
+        unsigned long long src = j;
+        if(bgr){ unsigned long long px = j / 3ull; src = px * 3ull + (2ull - (j - px * 3ull)); }
+        float x = linear[src];
+        uint32_t lo = 0u;
+        for(uint32_t step = 128u; step > 0u; step >>= 1) if(x >= s_thr[lo + step]) lo += step;   // s_thr[0] unused (byte >= 0 always)
+        packed |= lo << (8 * k);
+    }
+    if(first + 4ull <= num_values) out_words[w] = packed;
+    else {
+        unsigned char *tail = (unsigned char *) out_words + first;
+        for(unsigned long long k = 0; first + k < num_values; ++k) tail[k] = (unsigned char) (packed >> (8 * k));
+    }
+}
+
 // ---- merged trace kernel: closest-hit and any-hit rays with dynamic lane refill -----------
 // One launch serves the extension rays of iteration i+1 and the shadow rays of iteration i
 // (they are independent).  A workgroup owns a contiguous chunk of one queue; its lanes pull
@@ -1062,6 +1095,13 @@ void launch_finalize(hipStream_t s, const Tiling &tl, const float4 *accum, float
 void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, float *d_image){
     uint32_t g = ((uint32_t) (tl.W * tl.H) + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_untile, dim3(g), dim3(kBlock), 0, s, tl, d_gathered, d_image);
+}
+
+void launch_tonemap(hipStream_t s, const float *d_linear, void *d_bytes, unsigned long long num_values, int bgr, const float *d_thresholds){
+    if(num_values == 0) return;
+    unsigned long long words = (num_values + 3ull) / 4ull;
+    hipLaunchKernelGGL(k_tonemap, dim3((unsigned) ((words + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d_linear, (uint32_t *) d_bytes,
+                       num_values, bgr, d_thresholds);
 }
 
 void launch_probe_closest(hipStream_t s, const SceneDev &sc, const float *org, const float *dir, int n, int flags,
