@@ -5,11 +5,13 @@
 //   --width/--height  override the scene's R line        --seed N   reproducible streams
 //   --max-depth N     eye depth (reference: EYE_DEPTH 4)  --obj FILE append an OBJ's faces (current material: 0.7 grey diffuse)
 //   --rr              optional unbiased Russian roulette (pt)
+//   --gpus N          render on N devices of this node inside the blocking call (image tiles, RCCL gather)
 // --mode pt and --mode bdpt are built (ppm is outside this library); bdpt renders the reference's CPU
 // estimator (run_cpu_bdpt) on the GPU.
 #include "scene_model.hpp"
 #include "../../../include/hpt.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
@@ -19,7 +21,7 @@
 #define LIGHT_DEPTH 4
 #define EYE_DEPTH 4
 
-namespace hpt_host { extern hpt_params g_run_params; extern bool g_seed_from_clock; }
+namespace hpt_host { extern hpt_params g_run_params; extern bool g_seed_from_clock; extern int g_devices; }
 
 int main(int argc, char **argv){
     int spp = 8, spl = 8;
@@ -40,6 +42,7 @@ int main(int argc, char **argv){
         else if(arg == "--max-depth" && i + 1 < argc) max_depth = std::stoi(argv[++i]);
         else if(arg == "--obj" && i + 1 < argc) obj_file = argv[++i];
         else if(arg == "--rr") hpt_host::g_run_params.flags |= HPT_FLAG_RUSSIAN_ROULETTE;
+        else if(arg == "--gpus" && i + 1 < argc) hpt_host::g_devices = std::max(1, std::stoi(argv[++i]));
         else if(arg == "--help" || arg == "-h"){
             std::cout << "Usage: pt_cli [options]\n"
                       << "Options:\n"
@@ -53,7 +56,8 @@ int main(int argc, char **argv){
                       << "  --seed <int>      reproducible random streams (default: clock)\n"
                       << "  --max-depth <int> eye depth (default: 4)\n"
                       << "  --obj <file>      append the faces of a Wavefront OBJ\n"
-                      << "  --rr              unbiased Russian roulette (pt mode; not in the reference, off by default)\n";
+                      << "  --rr              unbiased Russian roulette (pt mode; not in the reference, off by default)\n"
+                      << "  --gpus <int>      devices of this node to render on (image tiles, RCCL gather; default: 1)\n";
             return 0;
         }
     }
@@ -79,6 +83,7 @@ int main(int argc, char **argv){
         if(n < 0){ std::cerr << "[Error] " << err << "\n"; return -1; }
         std::cout << "OBJ triangles: " << n << std::endl;
     }
+    std::cout << "[Parse] " << scene.parse_ms << " ms\n";
     std::cout << "Ball:" << std::endl << scene.ball_cnt << std::endl;
     std::cout << "Triangle:" << std::endl << scene.tri_cnt << std::endl;
     std::cout << "Light:" << std::endl << scene.lights.size() << std::endl;
@@ -90,8 +95,8 @@ int main(int argc, char **argv){
     std::vector<float3> frame_results((size_t) W * H);
 
     std::cout << "[Init] Transferring Data to the GPU...\n";
-    if(mode == "bdpt") move_data_to_cuda_bdpt(scene.groups, scene.lights, spl);
-    else move_data_to_cuda_pt(scene.groups, scene.lights, spl);
+    if(mode == "bdpt") move_data_to_cuda_bdpt(scene.groups(), scene.lights, spl);
+    else move_data_to_cuda_pt(scene.groups(), scene.lights, spl);
     if(seed >= 0){ hpt_host::g_seed_from_clock = false; hpt_host::g_run_params.seed = (uint64_t) seed; }
 
     std::cout << "[Render] Starting Render...\n";

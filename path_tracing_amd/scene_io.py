@@ -430,28 +430,115 @@ def cornell_random_triangles(n: int, seed: int = 12345, edge: float = 0.01):
     return lights, np.zeros(0, SPHERE), tris
 
 
+def _triangle_block_text(v9: np.ndarray) -> str:
+    """'T x0 y0 z0 ... z2' lines for an [n, 9] float32 array; shortest round-trip float32 decimals."""
+    if len(v9) == 0:
+        return ""
+    try:
+        import io
+        import pyarrow as pa
+        import pyarrow.csv as pacsv
+        cols = [pa.array(np.full(len(v9), "T"))] + [pa.array(np.ascontiguousarray(v9[:, k], f32)) for k in range(9)]
+        table = pa.Table.from_arrays(cols, names=["t"] + ["c%d" % k for k in range(9)])
+        buf = io.BytesIO()
+        pacsv.write_csv(table, buf, pacsv.WriteOptions(include_header=False, delimiter=" ", quoting_style="none"))
+        return buf.getvalue().decode("ascii")
+    except Exception:
+        return "".join("T " + " ".join("%.9g" % x for x in row) + "\n" for row in v9)
+
+
 def scene_to_text(lights, spheres, tris, W, H, eye=CORNELL_EYE, look=CORNELL_LOOK, up=CORNELL_UP, fov=50.0) -> str:
-    """Writes boundary arrays back out in the reference's text grammar ('T'/'S'/'M'/'L' lines)."""
-    out = ["E %g %g %g" % tuple(eye), "V %g %g %g %g %g %g" % (tuple(look) + tuple(up)), "F %g" % fov, "R %d %d" % (W, H)]
+    """Writes boundary arrays back out in the reference's text grammar ('T'/'S'/'M'/'L' lines, SURVEY
+    Appendix A): triangles in array order (one 'M' line per run of equal materials), then spheres, then lights."""
+    out = ["E %.9g %.9g %.9g\n" % tuple(eye), "V %.9g %.9g %.9g %.9g %.9g %.9g\n" % (tuple(look) + tuple(up)), "F %.9g\n" % fov, "R %d %d\n" % (W, H)]
+
+    def mat_line(m):
+        return "M %.9g %.9g %.9g %.9g %.9g %.9g\n" % (float(m["base_color"][0]), float(m["base_color"][1]), float(m["base_color"][2]),
+                                                      float(m["roughness"]), float(m["metallic"]), float(m["eta"]))
+
     last = None
-    for kind, arr in (("T", tris), ("S", spheres)):
-        for rec in arr:
-            m = rec["mtl"]
-            key = (float(m["base_color"][0]), float(m["base_color"][1]), float(m["base_color"][2]),
-                   float(m["roughness"]), float(m["metallic"]), float(m["eta"]))
-            if key != last:
-                out.append("M %.9g %.9g %.9g %.9g %.9g %.9g" % key)
-                last = key
-            if kind == "T":
-                out.append("T " + " ".join("%.9g" % x for x in np.concatenate([rec["v0"], rec["v1"], rec["v2"]])))
-            else:
-                out.append("S %.9g %.9g %.9g %.9g" % (rec["center"][0], rec["center"][1], rec["center"][2], rec["r"]))
+    if len(tris):
+        keys = np.concatenate([tris["mtl"]["base_color"].reshape(-1, 3), tris["mtl"]["roughness"].reshape(-1, 1),
+                               tris["mtl"]["metallic"].reshape(-1, 1), tris["mtl"]["eta"].reshape(-1, 1)], axis=1).astype(f32)
+        change = np.flatnonzero(np.any(keys[1:] != keys[:-1], axis=1)) + 1
+        starts = np.concatenate([[0], change, [len(tris)]])
+        v9 = np.concatenate([tris["v0"], tris["v1"], tris["v2"]], axis=1).astype(f32)
+        for a, b in zip(starts[:-1], starts[1:]):
+            out.append(mat_line(tris[a]["mtl"]))
+            out.append(_triangle_block_text(v9[a:b]))
+        last = tuple(keys[-1])
+    for rec in spheres:
+        m = rec["mtl"]
+        key = (f32(m["base_color"][0]), f32(m["base_color"][1]), f32(m["base_color"][2]), f32(m["roughness"]), f32(m["metallic"]), f32(m["eta"]))
+        if last is None or tuple(key) != tuple(last):
+            out.append(mat_line(m))
+            last = key
+        out.append("S %.9g %.9g %.9g %.9g\n" % (rec["center"][0], rec["center"][1], rec["center"][2], rec["r"]))
     for L in lights:
         deg = float(L["cutoff"]) / 0.017453292519943295
-        out.append("L %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d %.9g" % (
+        out.append("L %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d %.9g\n" % (
             L["pos"][0], L["pos"][1], L["pos"][2], L["dir"][0], L["dir"][1], L["dir"][2],
             L["illum"][0], L["illum"][1], L["illum"][2], deg, int(L["is_parallel"]), L["light_ball"]["r"]))
-    return "\n".join(out) + "\n"
+    return "".join(out)
+
+
+def write_obj(path: str, tris, quads: bool = False) -> None:
+    """Writes triangles as a Wavefront OBJ ('v' / 'f' lines, three new vertices per face; faces reference them with
+    negative, i.e. relative, indices on every other face to exercise both forms)."""
+    with open(path, "w") as fh:
+        fh.write("# %d triangles\no mesh\n" % len(tris))
+        for i, t in enumerate(tris):
+            for k in ("v0", "v1", "v2"):
+                fh.write("v %.9g %.9g %.9g\n" % tuple(t[k]))
+            if i % 2 == 0:
+                fh.write("f %d/1/1 %d/2/1 %d/3/1\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+            else:
+                fh.write("f -3 -2//7 -1\n")
+
+
+_HOST = None
+
+
+def _host_lib():
+    global _HOST
+    if _HOST is None:
+        import ctypes
+        import os
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhpt_host.so")
+        if not os.path.exists(so):
+            raise RuntimeError("libhpt_host.so not built: run `make -C path_tracing_amd/csrc`")
+        _HOST = ctypes.CDLL(so)
+        _HOST.hpt_host_flatten_file.restype = ctypes.c_int
+    return _HOST
+
+
+def load_scene_fast(path: str, obj: bool = False, W: int = 0, H: int = 0) -> dict:
+    """Scene text (or, obj=True, a Wavefront OBJ) through the C++ front-end (csrc/host/: mapped file +
+    tokenizer): the boundary arrays flatten_for_pt would give, the (kind, index, group) ordering, the camera
+    description and -- when W, H are given -- the CudaCamera the CLI would use."""
+    import ctypes as C
+    lib = _host_lib()
+    nl, ns, nt = C.c_int(), C.c_int(), C.c_int()
+    pl, ps, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    pk, pi, pg = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    cam = np.zeros((), CAMERA)
+    res = (C.c_int * 2)()
+    ms = C.c_double()
+    desc = (C.c_float * 10)()
+    rc = lib.hpt_host_flatten_file(path.encode(), 1 if obj else 0, C.byref(nl), C.byref(ns), C.byref(nt), C.byref(pl), C.byref(ps), C.byref(pt),
+                                   C.byref(pk), C.byref(pi), C.byref(pg), cam.ctypes.data_as(C.c_void_p), int(W), int(H), res, C.byref(ms), desc)
+    if rc != 0:
+        raise IOError("cannot read %s" % path)
+
+    def grab(p, n, dt):
+        return np.frombuffer(C.string_at(p, n * np.dtype(dt).itemsize), dt).copy() if n else np.zeros(0, dt)
+
+    nobj = ns.value + nt.value
+    d = np.array(list(desc), f32)
+    return dict(lights=grab(pl, nl.value, LIGHT), spheres=grab(ps, ns.value, SPHERE), tris=grab(pt, nt.value, TRIANGLE),
+                order=(grab(pk, nobj, np.int32), grab(pi, nobj, np.int32), grab(pg, nobj, np.int32)),
+                eye=d[0:3], look_at=d[3:6], view_up=d[6:9], fov=float(d[9]), resolution=(res[0], res[1]),
+                camera=cam if W > 0 and H > 0 else None, parse_ms=ms.value)
 
 
 def object_order(scene_desc=None, spheres=None, tris=None):
