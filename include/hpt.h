@@ -211,6 +211,14 @@ int hpt_multi_render_bdpt(hpt_multi *multi, const void *camera, int W, int H, in
 int hpt_multi_get_timing(const hpt_multi *multi, double *render_ms_per_device, double *gather_ms, double *total_ms);
 int hpt_wrapper_set_devices(int num_devices);
 
+/* Function-level probe of the device BSDF code (tests): evaluates, for n caller-given records, the
+ * device versions of bsdf_evaluate / bsdf_pdf / bsdf_sample, FrDielectric, FrSchlick, the GGX D / Lambda / G terms,
+ * the visible-normal sample, the local frame, sin/cos(2 pi u), is_valid_color and clamp_radiance (reference
+ * include/geometric.cuh:119-235, 419-562) exactly as the shading kernel calls them.  24 floats in and 40 floats out per
+ * record; the layout is documented at k_probe_functions (path_tracing_amd/csrc/pt_kernels.hip) and mirrored by
+ * oracle_function_kats (oracle/pt_oracle.cpp). */
+int hpt_probe_functions(const float *records_in, int n, float *results_out);
+
 /* ---- 8-bit output stage on the device -------------------------------------------------------------
  * Replaces the per-pixel loop of the reference CLI, src/main_cli.cpp:225-242: per channel clamp to [0, 1],
  * pow(x, 1/2.2), x 255, truncate.  The device looks the byte up in a table of 255 thresholds that the host

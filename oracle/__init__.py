@@ -110,6 +110,14 @@ def bsdf_sample(mat6, wo, n, u3, cur_eta=1.0, trig_mode=0):
     return dict(wi=out[0:3].copy(), f=out[3:6].copy(), pdf=float(out[6]), is_delta=bool(out[7]), new_eta=float(out[8]))
 
 
+def function_kats(records):
+    """[n, 24] float32 records -> [n, 40] results of the restated reference functions (layout: oracle_function_kats)."""
+    rec = np.ascontiguousarray(records, np.float32).reshape(-1, 24)
+    out = np.zeros((len(rec), 40), np.float32)
+    lib().oracle_function_kats(_p(rec), len(rec), _p(out))
+    return out
+
+
 def closest_hits(lights, spheres, tris, ro, rd):
     ro = np.ascontiguousarray(ro, np.float32)
     rd = np.ascontiguousarray(rd, np.float32)

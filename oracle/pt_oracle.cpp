@@ -362,6 +362,40 @@ void oracle_bsdf_sample(int trig_mode, const float *mat7, const float *wo, const
     bsdf_sample(trig_mode, m, v3(wo[0], wo[1], wo[2]), v3(n[0], n[1], n[2]), u3[0], u3[1], u3[2], cur_eta, wi, f, pdf, d, ne);
     out[0] = wi.x; out[1] = wi.y; out[2] = wi.z; out[3] = f.x; out[4] = f.y; out[5] = f.z; out[6] = pdf; out[7] = d ? 1.0f : 0.0f; out[8] = ne;
 }
+// Function-level known-answer table: the restated reference functions (ref_math.hpp: separate bsdf_evaluate / bsdf_pdf /
+// bsdf_sample, each rebuilding its own frame like geometric.cuh:419-562) on n records.  Same record layout as the
+// device probe k_probe_functions (24 floats in, 40 floats out).
+void oracle_function_kats(const float *in, int n, float *out){
+#pragma omp parallel for schedule(static)
+    for(int i = 0; i < n; ++i){
+        const float *r = in + (size_t) i * 24;
+        float *o = out + (size_t) i * 40;
+        RMat m; m.base_color = v3(r[0], r[1], r[2]); m.roughness = r[3]; m.metallic = r[4]; m.eta = r[5]; m.type = 0;
+        V3 N = v3(r[6], r[7], r[8]), wo_w = v3(r[9], r[10], r[11]), wi_w = v3(r[12], r[13], r[14]);
+        V3 f = bsdf_evaluate(m, wo_w, wi_w, N);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = bsdf_pdf(m, wo_w, wi_w, N);
+        V3 swi, sf; float spdf, ne; bool d;
+        bsdf_sample(0, m, wo_w, N, r[15], r[16], r[17], r[18], swi, sf, spdf, d, ne);
+        o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = d ? 1.0f : 0.0f; o[12] = ne;
+        o[13] = fr_dielectric(r[19], r[20], r[21]);
+        V3 sch = fr_schlick(r[19], m.base_color);
+        o[14] = sch.x; o[15] = sch.y; o[16] = sch.z;
+        V3 T, B; build_local_frame(N, T, B);
+        V3 wo_l = world_to_local(wo_w, T, B, N), wi_l = world_to_local(wi_w, T, B, N);
+        const float alpha = roughness_to_alpha(m.roughness);
+        o[17] = tr_D(wi_l, alpha); o[18] = tr_lambda(wi_l, alpha); o[19] = tr_G(wo_l, wi_l, alpha);
+        float sn, cs; sincos_2pi_poly(r[17], sn, cs);
+        o[20] = sn; o[21] = cs;
+        V3 vn = sample_vndf(0, wo_l.z > 0 ? wo_l : wo_l * -1.0f, alpha, r[16], r[17]);
+        o[22] = vn.x; o[23] = vn.y; o[24] = vn.z;
+        o[25] = is_valid_color(f) ? 1.0f : 0.0f;
+        V3 cl = clamp_radiance(f * 20.0f, 15.0f);
+        o[26] = cl.x; o[27] = cl.y; o[28] = cl.z;
+        o[29] = T.x; o[30] = T.y; o[31] = T.z; o[32] = B.x; o[33] = B.y; o[34] = B.z;
+        o[35] = wo_l.x; o[36] = wo_l.y; o[37] = wo_l.z;
+        o[38] = 0.0f; o[39] = 0.0f;
+    }
+}
 // brute-force closest hit for a batch of rays: out t (1e20 = miss) and prim ordinal (-1 = miss)
 void oracle_closest_hits(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
                          const float *ro, const float *rd, int nrays, float *t_out, int *prim_out){

@@ -78,7 +78,8 @@ def load_library() -> C.CDLL:
                      "hpt_render_bdpt", "hpt_render_bdpt_device", "hpt_bdpt_render_wrapper",
                      "hpt_pt_render_wrapper", "hpt_get_stats", "hpt_trace_closest", "hpt_trace_visibility",
                      "hpt_device_count", "hpt_multi_create", "hpt_multi_num_devices", "hpt_multi_set_groups",
-                     "hpt_multi_render_pt", "hpt_multi_render_bdpt", "hpt_multi_get_timing", "hpt_wrapper_set_devices"):
+                     "hpt_multi_render_pt", "hpt_multi_render_bdpt", "hpt_multi_get_timing", "hpt_wrapper_set_devices",
+                     "hpt_probe_functions", "hpt_tonemap", "hpt_tonemap_host"):
             getattr(lib, name).restype = C.c_int
         lib.hpt_scene_destroy.restype = None
         lib.hpt_wrapper_cache_clear.restype = None
@@ -267,6 +268,22 @@ class MultiScene:
         g = C.c_double(); t = C.c_double()
         _check(self._lib.hpt_multi_get_timing(self._h, per, C.byref(g), C.byref(t)))
         return {"render_ms_per_device": list(per), "gather_ms": g.value, "total_ms": t.value}
+
+
+def probe_functions(records) -> np.ndarray:
+    """Device BSDF / Fresnel / GGX functions on [n, 24] float32 records -> [n, 40] results (tests; include/hpt.h)."""
+    rec = np.ascontiguousarray(records, np.float32).reshape(-1, 24)
+    out = np.zeros((len(rec), 40), np.float32)
+    _check(load_library().hpt_probe_functions(_vp(rec), len(rec), _vp(out)))
+    return out
+
+
+def tonemap(image) -> np.ndarray:
+    """8-bit output stage on the device (reference src/main_cli.cpp:225-242): [H, W, 3] float32 -> uint8 RGB."""
+    img = np.ascontiguousarray(image, np.float32)
+    out = np.zeros(img.shape, np.uint8)
+    _check(load_library().hpt_tonemap_host(_vp(img), _vp(out), C.c_int64(img.size // 3), 0))
+    return out
 
 
 def wrapper_set_devices(n: int) -> None:

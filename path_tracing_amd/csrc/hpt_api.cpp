@@ -1058,6 +1058,19 @@ int hpt_trace_closest(hpt_scene *s, const float *origins, const float *dirs, int
     return HPT_OK;
 }
 
+int hpt_probe_functions(const float *records_in, int n, float *results_out){
+    if(n < 0 || (n > 0 && (!records_in || !results_out))) return fail(HPT_ERR_INVALID, "bad argument");
+    if(n == 0) return HPT_OK;
+    DevBuf d_in, d_out;
+    HIP_TRY(d_in.alloc((size_t) n * 24 * sizeof(float)));
+    HIP_TRY(d_out.alloc((size_t) n * 40 * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_in.p, records_in, (size_t) n * 24 * sizeof(float), hipMemcpyHostToDevice));
+    launch_probe_functions(nullptr, d_in.as<float>(), n, d_out.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(results_out, d_out.p, (size_t) n * 40 * sizeof(float), hipMemcpyDeviceToHost));
+    return HPT_OK;
+}
+
 int hpt_scene_set_groups(hpt_scene *s, const int32_t *obj_kind, const int32_t *obj_index, const int32_t *obj_group, int nobj){
     if(!s) return fail(HPT_ERR_INVALID, "null scene");
     if(nobj < 0 || (nobj > 0 && (!obj_kind || !obj_index || !obj_group))) return fail(HPT_ERR_INVALID, "bad group arrays");

@@ -91,6 +91,8 @@ void launch_untile(hipStream_t s, const Tiling &tl, const float *d_gathered, flo
 // 8-bit output stage: num_values = 3 * pixels floats in, as many bytes out (d_bytes 4-byte aligned); d_thresholds: 256 floats
 void launch_tonemap(hipStream_t s, const float *d_linear, void *d_bytes, unsigned long long num_values, int bgr, const float *d_thresholds);
 
+// function-level probe (tests): 24 floats in, 40 floats out per record (layout: k_probe_functions)
+void launch_probe_functions(hipStream_t s, const float *d_in, int n, float *d_out);
 // ray-level probes (tests)
 void launch_probe_closest(hipStream_t s, const SceneDev &sc, const float *org, const float *dir, int n, int flags,
                           float *t_out, int32_t *prim_out);

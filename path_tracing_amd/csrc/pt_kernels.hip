@@ -976,6 +976,52 @@ void k_probe_visibility(SceneDev sc, const float *p1, const float *p2, int n, in
     vis_out[i] = segment_visible<BRUTE, false>(sc, a, d, dist - 1e-3f, s_stack + threadIdx.x, tally) ? 1 : 0;
 }
 
+// Function-level probe (tests): the device versions of the reference's BSDF / Fresnel / GGX / frame
+// functions (reference include/geometric.cuh:119-235, 419-562) on caller-given inputs, called the way k_shade calls
+// them -- one shared ShadeCtx per hit, the merged value+pdf query, the precomputed diffuse lobe and Lambda(wo).
+// in:  24 floats per record   0-5 material (base rgb, roughness, metallic, eta) | 6-8 N | 9-11 wo | 12-14 wi |
+//                             15-17 u_rr u1 u2 | 18 current eta | 19 cosI | 20 etaI | 21 etaT
+// out: 40 floats per record   0-2 f(wo, wi) 3 pdf | 4-6 sampled wi 7-9 f 10 pdf 11 is_delta 12 new_eta |
+//                             13 FrDielectric(cosI, etaI, etaT) 14-16 FrSchlick(cosI, base) | 17 D(wi_l) 18 Lambda(wi_l)
+//                             19 G(wo_l, wi_l) | 20 sin 21 cos of 2 pi u2 | 22-24 visible normal | 25 is_valid_color(f)
+//                             26-28 clamp_radiance(20 f, 15) | 29-31 T 32-34 B of the local frame | 35-37 wo in that frame
+__global__ __launch_bounds__(kBlock)
+void k_probe_functions(const float *in, int n, float *out){
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if(i >= n) return;
+    const float *r = in + (size_t) i * 24;
+    float *o = out + (size_t) i * 40;
+    Mat m; m.base = mk3(r[0], r[1], r[2]); m.roughness = r[3]; m.metallic = r[4]; m.eta = r[5];
+    f3 N = mk3(r[6], r[7], r[8]), wo_w = mk3(r[9], r[10], r[11]), wi_w = mk3(r[12], r[13], r[14]);
+    ShadeCtx ctx = make_shade_ctx(N, wo_w);
+    ShadePre pre;
+    pre.diffuse = m.base / kPi * (1.0f - m.metallic);
+    const float alpha = roughness_to_alpha(m.roughness);
+    pre.lam_o = ggx_lambda(ctx.wo, alpha);
+    f3 f; float pdf;
+    bsdf_eval_pdf(m, ctx, wi_w, f, pdf, &pre);
+    o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
+    f3 swi, sf; float spdf, new_eta; bool is_delta;
+    bsdf_sample(m, ctx, r[15], r[16], r[17], r[18], swi, sf, spdf, is_delta, new_eta, &pre);
+    o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf;
+    o[11] = is_delta ? 1.0f : 0.0f; o[12] = new_eta;
+    o[13] = fr_dielectric(r[19], r[20], r[21]);
+    f3 sch = fr_schlick(r[19], m.base);
+    o[14] = sch.x; o[15] = sch.y; o[16] = sch.z;
+    f3 wi_l = to_local(wi_w, ctx.T, ctx.B, ctx.N);
+    o[17] = ggx_D(wi_l, alpha); o[18] = ggx_lambda(wi_l, alpha); o[19] = ggx_G(ctx.wo, wi_l, alpha);
+    float sn, cs; sincos_2pi(r[17], sn, cs);
+    o[20] = sn; o[21] = cs;
+    f3 vn = sample_visible_normal(ctx.wo.z > 0 ? ctx.wo : ctx.wo * -1.0f, alpha, sqrtf(r[16]), sn, cs);
+    o[22] = vn.x; o[23] = vn.y; o[24] = vn.z;
+    o[25] = is_valid_color(f) ? 1.0f : 0.0f;
+    f3 cl = clamp_radiance(f * 20.0f, 15.0f);
+    o[26] = cl.x; o[27] = cl.y; o[28] = cl.z;
+    o[29] = ctx.T.x; o[30] = ctx.T.y; o[31] = ctx.T.z; o[32] = ctx.B.x; o[33] = ctx.B.y; o[34] = ctx.B.z;
+    o[35] = ctx.wo.x; o[36] = ctx.wo.y; o[37] = ctx.wo.z;
+    o[38] = 0.0f; o[39] = 0.0f;
+}
+
 uint32_t grid_for(uint32_t items){
     uint32_t g = (items + kBlock - 1) / kBlock;
     if(g < 1u) g = 1u;
@@ -1102,6 +1148,11 @@ void launch_tonemap(hipStream_t s, const float *d_linear, void *d_bytes, unsigne
     unsigned long long words = (num_values + 3ull) / 4ull;
     hipLaunchKernelGGL(k_tonemap, dim3((unsigned) ((words + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d_linear, (uint32_t *) d_bytes,
                        num_values, bgr, d_thresholds);
+}
+
+void launch_probe_functions(hipStream_t s, const float *d_in, int n, float *d_out){
+    if(n <= 0) return;
+    hipLaunchKernelGGL(k_probe_functions, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_in, n, d_out);
 }
 
 void launch_probe_closest(hipStream_t s, const SceneDev &sc, const float *org, const float *dir, int n, int flags,

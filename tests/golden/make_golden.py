@@ -37,7 +37,19 @@ CASES = [  # name, W, H, depth, spp, seed
 ]
 
 
+def function_table(n_per_class=64, seed=99):
+    """kat_functions.npz: the oracle's BSDF / Fresnel / GGX functions on seeded records (tests/kat_records.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from kat_records import records
+    names, rec = records(n_per_class, seed)
+    out = oracle.function_kats(rec)
+    path = os.path.join(HERE, "kat_functions.npz")
+    np.savez_compressed(path, records=rec, results=out, n_per_class=n_per_class, seed=seed)
+    print(path, rec.shape, out.shape)
+
+
 def main():
+    function_table()
     for name, W, H, depth, spp, seed in CASES:
         (L, sp, tr), (eye, look, up) = scene_arrays(name)
         cam = S.make_camera(eye, look, up, 50.0, W, H)
