@@ -67,10 +67,11 @@ def load_library() -> C.CDLL:
     """Loads csrc/libhpt.so; raises HptError if it has not been built (no fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise HptError("libhpt.so not built: run `make -C path_tracing_amd/csrc` "
-                           "(or __graft_entry__.build()); there is no CPU fallback")
-        lib = C.CDLL(LIB_PATH)
+        path = os.environ.get("HPT_LIBRARY") or LIB_PATH        # HPT_LIBRARY: another build of libhpt.so (development A/B runs)
+        if not os.path.exists(path):
+            raise HptError("%s not built: run `make -C path_tracing_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback" % path)
+        lib = C.CDLL(path)
         lib.hpt_last_error.restype = C.c_char_p
         lib.hpt_local_pixels.restype = C.c_int64
         lib.hpt_local_pixels.argtypes = [C.c_int, C.c_int, C.POINTER(Params)]

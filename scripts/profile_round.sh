@@ -1,21 +1,30 @@
 #!/bin/bash
-# Round profile: kernel-trace stats of the bench command + FETCH_SIZE / WRITE_SIZE passes (separate runs).
-# Usage on the GPU box:  bash scripts/profile_round.sh <tag>
+# Round profile of the bench workload.  Usage on the GPU box:  bash scripts/profile_round.sh <tag>
+#   trace / trace_single   rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1` (two pipelines / one)
+#   pass_*                 one 64-spp pass (`--steps 1 --warmup 0 --spp 64 --single-pipeline`, nothing else rendered:
+#                          no counting render, no exclusive step), one PMC counter set per run -- counters are never
+#                          combined with anything but --kernel-trace
+# Results land in gpurun_out/<tag>/; scripts/profile_summarize.py <tag> turns them into profiles/<tag>_*.
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-TAG="${1:-r01}"
+TAG="${1:-r02}"
 OUT="$ROOT/gpurun_out/$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-exclusive-step > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-exclusive-step > "$OUT/trace.log" 2> "$OUT/trace.err"
 echo "trace exit $?"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --single-pipeline > "$OUT/trace_single.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --single-pipeline --no-count-step > "$OUT/trace_single.log" 2> "$OUT/trace_single.err"
 echo "trace (single pipeline) exit $?"
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --single-pipeline > "$OUT/pmc_$C.log" 2>&1
-  echo "pmc $C exit $?"
-done
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/pmc_TCC" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --single-pipeline > "$OUT/pmc_TCC.log" 2>&1
-echo "pmc TCC exit $?"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_SQ" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --single-pipeline > "$OUT/pmc_SQ.log" 2>&1
-echo "pmc SQ exit $?"
+ONE="--steps 1 --warmup 0 --spp 64 --no-cpu-baseline --single-pipeline --no-count-step"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/pass_timeline" -- python3 "$ROOT/bench.py" $ONE > "$OUT/pass_timeline.log" 2> "$OUT/pass_timeline.err"
+echo "pass timeline exit $?"
+pmc () {
+  name="$1"; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 "$ROOT/bench.py" $ONE > "$OUT/pmc_$name.log" 2> "$OUT/pmc_$name.err"
+  echo "pmc $name exit $?"
+}
+pmc FETCH_SIZE FETCH_SIZE
+pmc WRITE_SIZE WRITE_SIZE
+pmc TCC TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pmc SQ SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE
+pmc SQ2 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD

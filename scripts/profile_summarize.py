@@ -1,6 +1,7 @@
 """Turns gpurun_out/<tag> (scripts/profile_round.sh) into the committed profiles/<tag>_* files."""
 import csv, glob, json, os, sys, collections, shutil
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01b"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
@@ -15,7 +16,7 @@ def kname(n):
         if k in n: return k
     return None
 out = collections.defaultdict(dict)
-for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ"):
+for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ", "SQ2"):
     fs = glob.glob(os.path.join(src, "pmc_" + c, "*", "*_counter_collection.csv"))
     if not fs: continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
@@ -26,7 +27,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ"):
     for k in agg:
         for cn, v in agg[k].items(): out[k][cn] = v
         out[k]["dispatches"] = len(disp[k])
-res = {"tag": tag, "workload": "bench.py --steps 1 --warmup 0 --spp 64 --single-pipeline (cfg3 scene, 1024x1024; one 64 Mi-slot pass = the launch sizes of the 256-spp bench), one PMC counter set per run",
+import bench
+res = {"tag": tag, "kernel_source_sha": bench.kernel_source_sha(),
+       "workload": "bench.py --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --single-pipeline --no-count-step (cfg3 scene, 1024x1024; exactly ONE 64 Mi-slot pass "
+                   "is rendered = the launch sizes of the 256-spp bench), one PMC counter set per run",
        "note": "FETCH_SIZE/WRITE_SIZE are in KiB, summed over the kernel's dispatches; on gfx950 FETCH_SIZE tallies 128-B "
                "requests as 64 B (MI355X_MICROARCH.md, HBM section): read bytes = 2 x FETCH_SIZE x 1024; counts fabric-side "
                "requests including Infinity-Cache hits", "kernels": {}}
@@ -52,6 +56,32 @@ if kf and kf.get("hbm_bytes_per_launch") is not None:
     res["hbm_bytes_per_launch_note"] = "k_trace_first + k_trace_resume, per trace step"
 if kf and kf.get("valu_utilization") is not None:
     res["trace_valu_utilization"] = {"first": kf["valu_utilization"], "resume": (kr or {}).get("valu_utilization")}
+    res["trace_active_lanes"] = {"first": kf.get("valu_active_lanes_avg"), "resume": (kr or {}).get("valu_active_lanes_avg")}
+# path iterations of one 64-spp pass, from the counting render of the kernel-trace run's bench line
+try:
+    line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
+    b = json.loads(line)
+    iters = b["work"]["path_iterations_per_sample"] * 1024 * 1024 * 64
+    res["path_iterations_per_pass"] = iters
+    ksh = res["kernels"].get("k_shade")
+    if ksh and "read_bytes_corrected" in ksh and "write_bytes" in ksh:
+        res["shade_read_bytes_per_path_iteration"] = ksh["read_bytes_corrected"] / iters
+        res["shade_write_bytes_per_path_iteration"] = ksh["write_bytes"] / iters
+        res["shade_bytes_per_path_iteration"] = (ksh["read_bytes_corrected"] + ksh["write_bytes"]) / iters
+        res["shade_bytes_note"] = "k_shade fabric bytes of the pass / (path, bounce) shading steps of the pass; algorithmic figure (SURVEY 8d): 156 B"
+    if ksh and ksh.get("valu_utilization") is not None: res["shade_valu_utilization"] = ksh["valu_utilization"]
+    res["bench_line_of_the_kernel_trace_run"] = {k: b[k] for k in ("value", "ms_per_step") if k in b}
+except Exception as e:
+    res["path_iterations_per_pass"] = None; res["note_iters"] = "no bench line found: %s" % e
+# per-dispatch timeline of the single pass
+tl = glob.glob(os.path.join(src, "pass_timeline", "*", "*_kernel_trace.csv"))
+if tl:
+    rows = sorted(csv.DictReader(open(tl[0])), key=lambda r: int(r["Start_Timestamp"]))
+    seq = []
+    for r in rows:
+        k = kname(r["Kernel_Name"])
+        if k: seq.append([k, round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1)])
+    res["pass_timeline_us"] = seq
 json.dump(res, open(os.path.join("profiles", "%s_pmc_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(res, indent=1))
 print(open(os.path.join("profiles", "%s_kernel_stats.csv" % tag)).read()[:1500])
