@@ -63,10 +63,31 @@ class Stats(C.Structure):
 _lib = None
 
 
+def _share_the_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch's ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7) and
+    ask for it by the unversioned name, so if libhpt.so is loaded first it brings in /opt/rocm's copy, `import torch`
+    then loads a second one, and whichever initialises second finds no device ("No HIP GPUs are available" / "no
+    ROCm-capable device is detected").  When torch is installed but not imported yet, its copy is loaded here first;
+    libhpt.so's NEEDED libamdhip64.so.7 then resolves to it by soname, and a later `import torch` reuses it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library() -> C.CDLL:
     """Loads csrc/libhpt.so; raises HptError if it has not been built (no fallback)."""
     global _lib
     if _lib is None:
+        _share_the_hip_runtime_with_torch()
         path = os.environ.get("HPT_LIBRARY") or LIB_PATH        # HPT_LIBRARY: another build of libhpt.so (development A/B runs)
         if not os.path.exists(path):
             raise HptError("%s not built: run `make -C path_tracing_amd/csrc` "

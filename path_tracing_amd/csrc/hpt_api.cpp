@@ -800,7 +800,7 @@ int scene_upload(const HostScene &hs, const void *lights, int nl, const void *sp
     for(int a = 0; a < 3; ++a){ s->sd.qorigin[a] = hs.qorigin[a]; s->sd.qscale[a] = hs.qscale[a]; }
     s->sd.rounds = s->d_rounds; s->sd.mats = s->d_mats; s->sd.lights = s->d_lights;
     s->sd.num_rounds = ns + nl; s->sd.num_spheres = ns; s->sd.num_lights = nl; s->sd.num_tris = nt;
-    s->sd.num_mats = (int) hs.materials.size(); s->sd.pad = 0;
+    s->sd.num_mats = (int) hs.materials.size(); s->sd.num_nodes = (int) hs.qnodes.size();
     s->nl = nl; s->ns = ns; s->nt = nt;
     if(nl) s->h_lights.assign((const unsigned char *) lights, (const unsigned char *) lights + (size_t) nl * HPT_LIGHT_BYTES);
     if(ns) s->h_spheres.assign((const unsigned char *) spheres, (const unsigned char *) spheres + (size_t) ns * HPT_SPHERE_BYTES);

@@ -15,7 +15,7 @@ namespace hpt {
 
 constexpr uint32_t kLeafFlag = 0x80000000u;   // child code: leaf | first_tri << 3 | (count - 1)
 constexpr uint32_t kEmptyChild = 0xFFFFFFFFu; // child code of an absent child (box is inverted)
-constexpr int kMaxLeafTris = 4;
+constexpr int kMaxLeafTris = 2;              // triangles per leaf (A/B on four scenes, DESIGN.md section 5: 2 beats 1, 3, 4, 6, 8)
 constexpr int kMaxBvhDepth = 30;              // traversal stack holds kStackDepth entries
 constexpr int kStackDepth = 32;
 

@@ -15,7 +15,7 @@ struct SceneDev {
     const DevRound *rounds;     // spheres then light balls
     const DevMaterial *mats;
     const DevLight *lights;
-    int num_rounds, num_spheres, num_lights, num_tris, num_mats, pad;
+    int num_rounds, num_spheres, num_lights, num_tris, num_mats, num_nodes;
 };
 
 // Path state, structure of arrays indexed by path slot (one slot per (pixel, sample) in flight).
@@ -61,6 +61,8 @@ constexpr uint32_t kLongChunk = 2048;
 constexpr int kLongRefillMin = 16;
 constexpr int kLongNodeMin = 8;
 constexpr int kTraceBudget = 6;      // node steps a ray gets in the first trace launch before it is set aside
+constexpr int kTopLevels = 6;        // a budget of at most this many steps keeps a ray among the first kTopNodes nodes
+constexpr int kTopNodes = 64;        // (breadth-first order, scene_build.cpp): 2^kTopLevels - 1 = 63 nodes of 32 B, staged in LDS
 
 void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb,
                      uint32_t *qcount, int samples_this_pass, uint32_t first_sample, uint64_t seed,

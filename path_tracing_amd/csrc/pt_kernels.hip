@@ -687,10 +687,10 @@ constexpr int kNodeMin = 4;           // fewer lanes than this still walking nod
                                       // (A/B: off 42.1 ms, 2: 39.9, 4: 39.4, 8: 40.2, 16: 41.3, 32: 43.2)
 constexpr uint32_t kTraceShortQueue = 1u << 20;   // below this many rays a workgroup takes 256 instead of kTraceChunk
 
-template <bool ANY, bool COUNT, bool RESUME>
+template <bool ANY, bool COUNT, bool RESUME, bool TOP>
 HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *queue,
                          uint32_t end, uint32_t *stk, uint32_t *s_next, int refill_min, int node_min, WorkCounters *wc,
-                         uint32_t budget, uint32_t *s_long, uint32_t *s_nlong){
+                         uint32_t budget, uint32_t *s_long, uint32_t *s_nlong, const uint4 *top){
     bool active = false, exhausted = false;
     uint32_t path = 0u, cur = 0u, steps = 0u;
     int sp = 0;
@@ -807,7 +807,9 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                 if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_wave_steps += 64;   // one wave trip
             }
             if(!RESUME) steps += 1u;
-            const uint4 *n = sc.qnodes + (size_t) cur * 2;
+            // TOP: a ray with a budget of kTopLevels node steps only ever reaches nodes of depth < kTopLevels, which the
+            // breadth-first node order puts among the first kTopNodes: those sit in LDS (staged once per workgroup)
+            const uint4 *n = TOP ? top + cur * 2u : sc.qnodes + (size_t) cur * 2;
             uint4 w0 = n[0], w1 = n[1];
             // lmin.xyz lmax.xyz rmin.xyz rmax.xyz as 16-bit grid coordinates, then the two child codes
             float a0 = fmaf((float) (w0.x & 0xFFFFu), ix, ox), a1 = fmaf((float) (w0.y >> 16), ix, ox);
@@ -904,14 +906,20 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
 // is the same (closest hit with the ordinal tie-break, or the occlusion boolean, of the same ray).
 struct LongQueues { uint32_t *equeue, *ecount, *squeue, *scount; uint32_t budget; };
 
-template <bool COUNT, bool RESUME>
+template <bool COUNT, bool RESUME, bool TOP>
 __global__ __launch_bounds__(kBlock)
 void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, const uint32_t *ecount_ptr,
              const uint32_t *squeue, const uint32_t *scount_ptr, uint32_t chunk_rays, int refill_min, int node_min,
              int stack_words, LongQueues lq, WorkCounters *wc){
     extern __shared__ uint32_t s_dyn_stack[];        // [stack level][lane], sized by the BVH depth; then the long-ray list
     __shared__ uint32_t s_next, s_nlong, s_gbase;
+    __shared__ uint4 s_top[TOP ? kTopNodes * 2 : 1];  // the top of the quantised tree (first launch of a split step)
     uint32_t *s_long = s_dyn_stack + stack_words;
+    if(TOP){
+        const uint32_t words = (uint32_t) (sc.num_nodes < kTopNodes ? sc.num_nodes : kTopNodes) * 2u;
+        for(uint32_t i = threadIdx.x; i < words; i += kBlock) s_top[i] = sc.qnodes[i];
+        // (the first __syncthreads of the chunk loop below orders these stores before any traversal)
+    }
     uint32_t ecount = ecount_ptr ? *ecount_ptr : 0u, scount = scount_ptr ? *scount_ptr : 0u;
     // short queues (the delta-bounce tail) get one ray per lane so they spread over every CU
     uint32_t ce = ecount >= kTraceShortQueue ? chunk_rays : (uint32_t) kBlock;
@@ -926,10 +934,10 @@ void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, cons
         uint32_t end = begin + csize < total ? begin + csize : total;
         if(threadIdx.x == 0){ s_next = begin; s_nlong = 0u; }
         __syncthreads();
-        if(shadow) trace_chunk<true, COUNT, RESUME>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
-                                                    lq.budget, s_long, &s_nlong);
-        else trace_chunk<false, COUNT, RESUME>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
-                                               lq.budget, s_long, &s_nlong);
+        if(shadow) trace_chunk<true, COUNT, RESUME, TOP>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
+                                                         lq.budget, s_long, &s_nlong, s_top);
+        else trace_chunk<false, COUNT, RESUME, TOP>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
+                                                    lq.budget, s_long, &s_nlong, s_top);
         __syncthreads();
         if(!RESUME && lq.budget != 0u){
             uint32_t n = s_nlong;
@@ -1099,8 +1107,10 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
         lq.budget = (uint32_t) split->budget;
     }
     size_t lds = (size_t) stack_words * sizeof(uint32_t) + (lq.budget ? (size_t) chunk * sizeof(uint32_t) : 0);
-    if(count) hipLaunchKernelGGL((k_trace<true, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
-    else hipLaunchKernelGGL((k_trace<false, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
+    const bool top = lq.budget != 0u && lq.budget <= (uint32_t) kTopLevels && !(tuning & 0x80);       // tuning bit 7: node fetches from global memory (A/B)
+    if(count) hipLaunchKernelGGL((k_trace<true, false, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
+    else if(top) hipLaunchKernelGGL((k_trace<false, false, true>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
+    else hipLaunchKernelGGL((k_trace<false, false, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
 }
 
 // second launch of a split trace step: the rays launch_trace set aside.  Their number is only known on
@@ -1118,7 +1128,7 @@ void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBu
     uint64_t g = (uint64_t) per * ((extend ? 1u : 0u) + (shadow ? 1u : 0u));
     uint32_t g2 = g < 8192u ? (uint32_t) (g < 1u ? 1u : g) : 8192u;
     LongQueues none{};
-    hipLaunchKernelGGL((k_trace<false, true>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
+    hipLaunchKernelGGL((k_trace<false, true, false>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
                        extend ? split.equeue : nullptr, extend ? split.ecount : nullptr, shadow ? split.squeue : nullptr,
                        shadow ? split.scount : nullptr, chunk2, refill2, node_min2, stack_words, none, wc);
 }

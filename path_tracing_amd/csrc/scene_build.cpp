@@ -282,6 +282,27 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
     }
     hs.nodes.swap(B.nodes);
     hs.bvh_depth = B.max_depth_seen;
+    {   // breadth-first renumbering: node 0 stays the root and every node of depth d precedes every node of depth d + 1,
+        // so the nodes a ray can reach in its first k steps are the first 2^k - 1 at most (k_trace keeps those in LDS)
+        const size_t n = hs.nodes.size();
+        std::vector<uint32_t> order; order.reserve(n);
+        std::vector<uint32_t> new_index(n, 0u);
+        order.push_back(0u);
+        for(size_t head = 0; head < order.size(); ++head){
+            const BvhNode &nd = hs.nodes[order[head]];
+            for(uint32_t c : { nd.left, nd.right })
+                if(c != kEmptyChild && !(c & kLeafFlag)){ new_index[c] = (uint32_t) order.size(); order.push_back(c); }
+        }
+        if(order.size() != n) return "internal error: BVH nodes unreachable from the root";
+        std::vector<BvhNode> sorted(n);
+        for(size_t i = 0; i < n; ++i){
+            BvhNode nd = hs.nodes[order[i]];
+            if(nd.left != kEmptyChild && !(nd.left & kLeafFlag)) nd.left = new_index[nd.left];
+            if(nd.right != kEmptyChild && !(nd.right & kLeafFlag)) nd.right = new_index[nd.right];
+            sorted[i] = nd;
+        }
+        hs.nodes.swap(sorted);
+    }
     {   // quantised twin: 16-bit grid over the union of the (padded) node boxes
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for(const BvhNode &n : hs.nodes){

@@ -9,8 +9,8 @@ shutil.copy(ks, os.path.join("profiles", "%s_kernel_stats.csv" % tag))
 for ks1 in glob.glob(os.path.join(src, "trace_single", "*", "*_kernel_stats.csv")):
     shutil.copy(ks1, os.path.join("profiles", "%s_kernel_stats_single_pipeline.csv" % tag))
 def kname(n):
-    if "k_trace<false, false>" in n: return "k_trace_first"      # first launch of a trace step (every ray, budgeted)
-    if "k_trace<false, true>" in n: return "k_trace_resume"      # second launch (the rays set aside)
+    if "k_trace<false, false" in n: return "k_trace_first"      # first launch of a trace step (every ray, budgeted)
+    if "k_trace<false, true" in n: return "k_trace_resume"      # second launch (the rays set aside)
     if "k_trace<true" in n: return "k_trace_count"               # the counting render's plain traversal
     for k in ("k_trace", "k_shade", "k_generate", "k_resolve", "k_finalize", "k_untile", "k_extend", "k_connect"):
         if k in n: return k

@@ -176,3 +176,26 @@ def test_config3_full_shape_256spp(hpt, sio, oracle_mod):
     x0, y0, x1, y1 = 568, 384, 576, 392
     ref, _ = oracle_mod.pt_render(L, sp, tr, cam, W, H, 4, 256, seed=1, window=(x0, y0, x1, y1))
     assert_parity(full[y0:y1, x0:x1], ref[y0:y1, x0:x1])
+
+
+def test_library_and_torch_share_one_hip_runtime_whatever_the_import_order():
+    """libhpt.so loaded before torch used to leave two HIP runtimes in the process, and the second one to initialise
+    saw no device; path_tracing_amd.load_library() now loads torch's runtime first when torch is installed."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import path_tracing_amd as hpt\n"
+            "from path_tracing_amd import scene_io as S\n"
+            "hpt.load_library()\n"
+            "assert 'torch' not in sys.modules\n"
+            "import torch\n"
+            "torch.cuda.current_stream()\n"
+            "sc = S.load_scene(%r); L, sp, tr = S.flatten_for_pt(sc)\n"
+            "with hpt.Scene(L, sp, tr) as s: img = s.render_pt(S.camera_for(sc, 16, 16), 16, 16, 4, 1)\n"
+            "x = torch.ones(4, device='cuda').sum().item()\n"
+            "n = len(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+            "print('OK', x, float(img.mean()) > 0, n)\n") % (ROOT, os.path.join(ROOT, "tests", "golden", "scenes", "input.txt"))
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    assert "OK 4.0 True 1" in run.stdout
