@@ -79,27 +79,23 @@ struct hpt_scene {
     bool split_probe_pending = false; int split_probe_stride = 0, split_hold = 0;
     int num_cus = 256;
 
-    // workspace, grown on demand
-    size_t cap_paths = 0, cap_local = 0;
-    PathBuf pb{}; ShadowBuf sb{};
-    uint32_t *queue[2] = { nullptr, nullptr };   // path queues (ping-pong)
-    uint32_t *squeue = nullptr;                  // shadow queue (path slots)
-    uint32_t *lqueue[2] = { nullptr, nullptr };  // rays set aside by the first trace launch: closest-hit, shadow
-    // second pipeline (PT): two passes of a render are in flight at a time, each with its own path state,
-    // queues and counters, on its own stream -- the kernels of one fill the issue slots the other leaves idle
-    struct Pipe2 {
+    // workspace, grown on demand.  Two passes of a PT render are in flight at a time (render_local), each with its own
+    // path state, queues and counters (pass[0] on the caller's stream, pass[1] on p2_stream) -- the kernels of one
+    // fill the issue slots the other leaves idle; everything else (BDPT, probes) uses pass[0]
+    struct PassBuffers {
         size_t cap_paths = 0;
         PathBuf pb{}; ShadowBuf sb{};
-        uint32_t *queue[2] = { nullptr, nullptr }, *squeue = nullptr, *lqueue[2] = { nullptr, nullptr };
+        uint32_t *queue[2] = { nullptr, nullptr };   // path queues (ping-pong)
+        uint32_t *squeue = nullptr;                  // shadow queue (path slots)
+        uint32_t *lqueue[2] = { nullptr, nullptr };  // rays set aside by the first trace launch: closest-hit, shadow
         uint32_t *counters = nullptr; int n_counters = 0;
-        uint32_t *h_count = nullptr;
-        hipStream_t stream = nullptr; int priority = 0; hipEvent_t ev_fork = nullptr, ev_done = nullptr;
-    } p2;
+        uint32_t *h_count = nullptr;                 // pinned read-back word
+    } pass[2];
+    size_t cap_local = 0;
+    hipStream_t p2_stream = nullptr; int p2_priority = 0; hipEvent_t p2_fork = nullptr, p2_done = nullptr;
     const uint32_t *last_counters = nullptr;     // counters of the last pass rendered (either pipeline)
-    uint32_t *counters = nullptr; int n_counters = 0;
     float4 *accum = nullptr;
     WorkCounters *d_wc = nullptr;
-    uint32_t *h_count = nullptr;          // pinned read-back word
     float *d_local_own = nullptr; size_t cap_local_own = 0;
     float *d_image_own = nullptr; size_t cap_image_own = 0;
 
@@ -123,27 +119,20 @@ struct hpt_scene {
 
 namespace {
 
-void free_workspace(hpt_scene *s){
-    hipFree(s->pb.org_eta); hipFree(s->pb.dir_flags); hipFree(s->pb.thr); hipFree(s->pb.col);
-    hipFree(s->pb.rng); hipFree(s->pb.hit);
-    hipFree(s->sb.org_max); hipFree(s->sb.dir); hipFree(s->sb.contrib);
-    hipFree(s->queue[0]); hipFree(s->queue[1]); hipFree(s->squeue); s->squeue = nullptr;
-    hipFree(s->lqueue[0]); hipFree(s->lqueue[1]); s->lqueue[0] = s->lqueue[1] = nullptr;
-    s->pb = PathBuf{}; s->sb = ShadowBuf{}; s->queue[0] = s->queue[1] = nullptr; s->cap_paths = 0;
-}
+using PassBuffers = hpt_scene::PassBuffers;
 
-void free_pipe2(hpt_scene *s){
-    hpt_scene::Pipe2 &w = s->p2;
+void free_pass(PassBuffers &w){
     hipFree(w.pb.org_eta); hipFree(w.pb.dir_flags); hipFree(w.pb.thr); hipFree(w.pb.col); hipFree(w.pb.rng); hipFree(w.pb.hit);
     hipFree(w.sb.org_max); hipFree(w.sb.dir); hipFree(w.sb.contrib);
     hipFree(w.queue[0]); hipFree(w.queue[1]); hipFree(w.squeue); hipFree(w.lqueue[0]); hipFree(w.lqueue[1]);
-    w.pb = PathBuf{}; w.sb = ShadowBuf{}; w.queue[0] = w.queue[1] = w.squeue = w.lqueue[0] = w.lqueue[1] = nullptr; w.cap_paths = 0;
+    w.pb = PathBuf{}; w.sb = ShadowBuf{};
+    w.queue[0] = w.queue[1] = w.squeue = w.lqueue[0] = w.lqueue[1] = nullptr;
+    w.cap_paths = 0;
 }
 
-int ensure_pipe2(hpt_scene *s, size_t paths, int n_counters, hipStream_t caller){
-    hpt_scene::Pipe2 &w = s->p2;
+int ensure_pass(PassBuffers &w, size_t paths, int n_counters){
     if(paths > w.cap_paths){
-        free_pipe2(s);
+        free_pass(w);
         HIP_TRY(hipMalloc((void **) &w.pb.org_eta, paths * sizeof(float4)));
         HIP_TRY(hipMalloc((void **) &w.pb.dir_flags, paths * sizeof(float4)));
         HIP_TRY(hipMalloc((void **) &w.pb.thr, paths * sizeof(float4)));
@@ -161,11 +150,16 @@ int ensure_pipe2(hpt_scene *s, size_t paths, int n_counters, hipStream_t caller)
         w.cap_paths = paths;
     }
     if(n_counters > w.n_counters){
-        hipFree(w.counters); w.counters = nullptr;
+        hipFree(w.counters); w.counters = nullptr; w.n_counters = 0;
         HIP_TRY(hipMalloc((void **) &w.counters, (size_t) n_counters * sizeof(uint32_t)));
         w.n_counters = n_counters;
     }
     if(!w.h_count) HIP_TRY(hipHostMalloc((void **) &w.h_count, 64));
+    return HPT_OK;
+}
+
+// stream and events of the second pipeline
+int ensure_pipe2(hpt_scene *s, hipStream_t caller){
     // The two pipelines only overlap if their streams sit on different hardware queues.  The runtime maps streams
     // of one priority onto a small pool of queues (GPU_MAX_HW_QUEUES, 4 by default) by reference count, so once a
     // process holds a few more streams -- RCCL's, after a communicator exists -- a second stream of the caller's
@@ -176,49 +170,27 @@ int ensure_pipe2(hpt_scene *s, size_t paths, int n_counters, hipStream_t caller)
     HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
     if(hipStreamGetPriority(caller, &pr_caller) != hipSuccess){ (void) hipGetLastError(); pr_caller = 0; }
     const int want = (pr_caller == pr_greatest && pr_greatest != 0) ? 0 : pr_greatest;
-    if(w.stream && w.priority != want){ hipStreamSynchronize(w.stream); hipStreamDestroy(w.stream); w.stream = nullptr; }
-    if(!w.stream){
-        HIP_TRY(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, want));
-        w.priority = want;
+    if(s->p2_stream && s->p2_priority != want){ hipStreamSynchronize(s->p2_stream); hipStreamDestroy(s->p2_stream); s->p2_stream = nullptr; }
+    if(!s->p2_stream){
+        HIP_TRY(hipStreamCreateWithPriority(&s->p2_stream, hipStreamNonBlocking, want));
+        s->p2_priority = want;
     }
-    if(!w.ev_fork){
-        HIP_TRY(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+    if(!s->p2_fork){
+        HIP_TRY(hipEventCreateWithFlags(&s->p2_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->p2_done, hipEventDisableTiming));
     }
     return HPT_OK;
 }
 
 int ensure_workspace(hpt_scene *s, size_t paths, size_t n_local, int n_counters){
-    if(paths > s->cap_paths){
-        free_workspace(s);
-        HIP_TRY(hipMalloc((void **) &s->pb.org_eta, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &s->pb.dir_flags, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &s->pb.thr, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &s->pb.col, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &s->pb.rng, paths * sizeof(uint2)));
-        HIP_TRY(hipMalloc((void **) &s->pb.hit, paths * sizeof(uint2)));
-        HIP_TRY(hipMalloc((void **) &s->sb.org_max, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &s->sb.dir, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &s->sb.contrib, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void **) &s->queue[0], paths * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **) &s->queue[1], paths * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **) &s->squeue, paths * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **) &s->lqueue[0], paths * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **) &s->lqueue[1], paths * sizeof(uint32_t)));
-        s->cap_paths = paths;
-    }
+    int rc = ensure_pass(s->pass[0], paths, n_counters);
+    if(rc) return rc;
     if(n_local > s->cap_local){
-        hipFree(s->accum); s->accum = nullptr;
+        hipFree(s->accum); s->accum = nullptr; s->cap_local = 0;
         HIP_TRY(hipMalloc((void **) &s->accum, n_local * sizeof(float4)));
         s->cap_local = n_local;
     }
-    if(n_counters > s->n_counters){
-        hipFree(s->counters); s->counters = nullptr;
-        HIP_TRY(hipMalloc((void **) &s->counters, (size_t) n_counters * sizeof(uint32_t)));
-        s->n_counters = n_counters;
-    }
     if(!s->d_wc) HIP_TRY(hipMalloc((void **) &s->d_wc, sizeof(WorkCounters)));
-    if(!s->h_count) HIP_TRY(hipHostMalloc((void **) &s->h_count, 64));
     if(!s->ev_start){ HIP_TRY(hipEventCreate(&s->ev_start)); HIP_TRY(hipEventCreate(&s->ev_stop)); }
     return HPT_OK;
 }
@@ -279,7 +251,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     const bool timek = (flags & HPT_FLAG_TIME_KERNELS) != 0;
     const bool brute = (flags & HPT_FLAG_BRUTE_FORCE) != 0;
     const bool legacy = brute || (P.reserved & 1);          // separate extend/connect kernels (the scan variants)
-    const int kflags = (brute ? 1 : 0) | (count ? 2 : 0);
+    const int kflags = (brute ? 1 : 0) | (count ? 2 : 0) | ((flags >> 16) & 1 ? 4 : 0);      // flags bits 16-31: development switches
 
     // Samples in flight per pass: about 64 Mi path slots (9.5 GiB of path state, queues and shadow records:
     // nothing on a 288 GB device).  Fewer, larger passes amortise the low-occupancy tail iterations of every
@@ -305,7 +277,8 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     rc = ensure_workspace(s, paths, tl.n_local, n_counters);
     if(rc) return rc;
     if(dual){
-        rc = ensure_pipe2(s, paths, n_counters, stream);
+        rc = ensure_pass(s->pass[1], paths, n_counters);
+        if(rc == HPT_OK) rc = ensure_pipe2(s, stream);
         if(rc) return rc;
     }
 
@@ -350,17 +323,17 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
 
     // one pass in flight on one pipeline
     struct Pass {
-        PathBuf pb; ShadowBuf sb; uint32_t *queue[2], *squeue, *lqueue[2], *counters, *h_count; hipStream_t st;
+        PathBuf pb; ShadowBuf sb; uint32_t *queue[2], *squeue, *lqueue[2]; uint32_t *counters, *h_count; hipStream_t st;
         int sthis = 0, cur = 0, pending_shadow = -1; uint32_t slots = 0;
         uint32_t *qcnt = nullptr, *scnt = nullptr, *lecnt = nullptr, *lscnt = nullptr;
     };
     Pass pipe[2]{};
-    pipe[0].pb = s->pb; pipe[0].sb = s->sb; pipe[0].queue[0] = s->queue[0]; pipe[0].queue[1] = s->queue[1]; pipe[0].squeue = s->squeue;
-    pipe[0].lqueue[0] = s->lqueue[0]; pipe[0].lqueue[1] = s->lqueue[1]; pipe[0].counters = s->counters; pipe[0].h_count = s->h_count; pipe[0].st = stream;
-    if(dual){
-        hpt_scene::Pipe2 &w = s->p2;
-        pipe[1].pb = w.pb; pipe[1].sb = w.sb; pipe[1].queue[0] = w.queue[0]; pipe[1].queue[1] = w.queue[1]; pipe[1].squeue = w.squeue;
-        pipe[1].lqueue[0] = w.lqueue[0]; pipe[1].lqueue[1] = w.lqueue[1]; pipe[1].counters = w.counters; pipe[1].h_count = w.h_count; pipe[1].st = w.stream;
+    for(int k = 0; k < (dual ? 2 : 1); ++k){
+        const PassBuffers &w = s->pass[k];
+        Pass &q = pipe[k];
+        q.pb = w.pb; q.sb = w.sb; q.queue[0] = w.queue[0]; q.queue[1] = w.queue[1]; q.squeue = w.squeue;
+        q.lqueue[0] = w.lqueue[0]; q.lqueue[1] = w.lqueue[1];
+        q.counters = w.counters; q.h_count = w.h_count; q.st = k == 0 ? stream : s->p2_stream;
     }
     for(Pass &q : pipe){
         if(!q.counters) continue;
@@ -434,8 +407,8 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         if(second){
             // the second pipeline starts after everything already queued on the caller's stream (the previous
             // resolve of its radiance buffer included)
-            HIP_TRY(hipEventRecord(s->p2.ev_fork, stream));
-            HIP_TRY(hipStreamWaitEvent(s->p2.stream, s->p2.ev_fork, 0));
+            HIP_TRY(hipEventRecord(s->p2_fork, stream));
+            HIP_TRY(hipStreamWaitEvent(s->p2_stream, s->p2_fork, 0));
         }
         rc = begin_pass(pipe[0], done); if(rc) return rc;
         if(second){ rc = begin_pass(pipe[1], done + spass); if(rc) return rc; }
@@ -450,8 +423,8 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
           launch_resolve(stream, tl, pipe[0].pb, s->accum, pipe[0].sthis); }
         s->last_counters = pipe[0].counters;
         if(second){
-            HIP_TRY(hipEventRecord(s->p2.ev_done, s->p2.stream));
-            HIP_TRY(hipStreamWaitEvent(stream, s->p2.ev_done, 0));
+            HIP_TRY(hipEventRecord(s->p2_done, s->p2_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, s->p2_done, 0));
             LaunchTimer t(s, stream, timek, 3);
             launch_resolve(stream, tl, pipe[1].pb, s->accum, pipe[1].sthis);
             s->last_counters = pipe[1].counters;
@@ -648,33 +621,33 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
         for(int done = 0; done < spp; done += spass){
             int sthis = std::min(spass, spp - done);
             uint32_t nslots = (uint32_t) tl.n_local * (uint32_t) sthis;
-            HIP_TRY(hipMemsetAsync(s->counters, 0, (size_t) n_counters * sizeof(uint32_t), stream));
-            uint32_t *qcnt = s->counters, *ccnt = s->counters + (max_iters + 2);
+            HIP_TRY(hipMemsetAsync(s->pass[0].counters, 0, (size_t) n_counters * sizeof(uint32_t), stream));
+            uint32_t *qcnt = s->pass[0].counters, *ccnt = s->pass[0].counters + (max_iters + 2);
             { LaunchTimer t(s, stream, timek, 3);
-              launch_bdpt_generate(stream, tl, cam, s->pb, s->bp, &qcnt[0], sthis, (uint32_t) (P.sample_offset + done), P.seed); }
+              launch_bdpt_generate(stream, tl, cam, s->pass[0].pb, s->bp, &qcnt[0], sthis, (uint32_t) (P.sample_offset + done), P.seed); }
             int cur = 0;
             for(int it = 0; it < max_iters; ++it){
                 const int ci = it;                             // counter slot of this iteration
                 if(it >= eye_depth){
-                    HIP_TRY(hipMemcpyAsync(s->h_count, &qcnt[ci], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(s->pass[0].h_count, &qcnt[ci], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipStreamSynchronize(stream));
-                    if(*s->h_count == 0u) break;
+                    if(*s->pass[0].h_count == 0u) break;
                 }
-                const uint32_t *eq = it == 0 ? nullptr : s->queue[cur];
+                const uint32_t *eq = it == 0 ? nullptr : s->pass[0].queue[cur];
                 { LaunchTimer t(s, stream, timek, 0);
-                  launch_bdpt_extend(stream, s->bd, s->pb, eq, &qcnt[ci], nslots); }
+                  launch_bdpt_extend(stream, s->bd, s->pass[0].pb, eq, &qcnt[ci], nslots); }
                 { LaunchTimer t(s, stream, timek, 1);
-                  launch_bdpt_vertex(stream, s->bd, s->pb, s->bp, eq, &qcnt[ci], nslots, s->queue[cur ^ 1], &qcnt[ci + 1],
+                  launch_bdpt_vertex(stream, s->bd, s->pass[0].pb, s->bp, eq, &qcnt[ci], nslots, s->pass[0].queue[cur ^ 1], &qcnt[ci + 1],
                                      s->cqueue, &ccnt[ci], eye_depth, P.max_delta, (uint32_t) slots); }
                 { LaunchTimer t(s, stream, timek, 2);
-                  launch_bdpt_connect(stream, s->bd, s->pb, s->bp, s->d_lv, n_lv, light_depth, s->cqueue, &ccnt[ci], nslots,
+                  launch_bdpt_connect(stream, s->bd, s->pass[0].pb, s->bp, s->d_lv, n_lv, light_depth, s->cqueue, &ccnt[ci], nslots,
                                       cam.eye, (uint32_t) slots); }
                 { LaunchTimer t(s, stream, timek, 3);
-                  launch_bdpt_reduce(stream, s->pb, s->bp, n_lv, s->cqueue, &ccnt[ci], nslots); }
+                  launch_bdpt_reduce(stream, s->pass[0].pb, s->bp, n_lv, s->cqueue, &ccnt[ci], nslots); }
                 cur ^= 1;
             }
             { LaunchTimer t(s, stream, timek, 3);
-              launch_resolve(stream, tl, s->pb, s->accum, sthis); }
+              launch_resolve(stream, tl, s->pass[0].pb, s->accum, sthis); }
         }
     }
     float divisor = (P.flags & HPT_FLAG_OUTPUT_SUM) ? 1.0f : (float) spp;
@@ -839,15 +812,15 @@ int hpt_scene_create(const void *lights, int nl, const void *spheres, int ns, co
 
 void hpt_scene_destroy(hpt_scene *s){
     if(!s) return;
-    free_workspace(s);
-    hipFree(s->accum); hipFree(s->counters); hipFree(s->d_wc);
-    if(s->h_count) hipHostFree(s->h_count);
-    free_pipe2(s);
-    hipFree(s->p2.counters);
-    if(s->p2.h_count) hipHostFree(s->p2.h_count);
-    if(s->p2.ev_fork) hipEventDestroy(s->p2.ev_fork);
-    if(s->p2.ev_done) hipEventDestroy(s->p2.ev_done);
-    if(s->p2.stream) hipStreamDestroy(s->p2.stream);
+    for(PassBuffers &w : s->pass){
+        free_pass(w);
+        hipFree(w.counters);
+        if(w.h_count) hipHostFree(w.h_count);
+    }
+    hipFree(s->accum); hipFree(s->d_wc);
+    if(s->p2_fork) hipEventDestroy(s->p2_fork);
+    if(s->p2_done) hipEventDestroy(s->p2_done);
+    if(s->p2_stream) hipStreamDestroy(s->p2_stream);
     if(s->h_split) hipHostFree(s->h_split);
     if(s->ev_split) hipEventDestroy(s->ev_split);
     hipFree(s->d_local_own); hipFree(s->d_image_own);

@@ -1105,6 +1105,8 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
     if(split && split->budget > 0 && !count){
         lq.equeue = split->equeue; lq.ecount = split->ecount; lq.squeue = split->squeue; lq.scount = split->scount;
         lq.budget = (uint32_t) split->budget;
+        // a ray of this launch is set aside after `budget` node steps, so its stack never grows past that many entries
+        if(stack_levels > split->budget && !(flags & 4)) stack_words = (split->budget + 1) * kBlock;      // flags bit 2: development A/B
     }
     size_t lds = (size_t) stack_words * sizeof(uint32_t) + (lq.budget ? (size_t) chunk * sizeof(uint32_t) : 0);
     const bool top = lq.budget != 0u && lq.budget <= (uint32_t) kTopLevels && !(tuning & 0x80);       // tuning bit 7: node fetches from global memory (A/B)
