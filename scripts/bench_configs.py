@@ -1,52 +1,83 @@
-"""Timings of the BASELINE.json configs other than the headline one (bench.py covers configs[2])."""
-import sys, os, json
+"""Timings of every BASELINE.json configuration on one GPU (bench.py is the contract line for configs[2]).
+
+One JSON object on stdout: per configuration the device time of a render (median of `reps`), Msamples/s, the
+per-kernel-class times of the last render (HIP events around every launch) and, for the PT configurations, the work
+counts and the two rooflines bench.py reports (algorithmic GB/s against HBM peak; useful lane-operations against the
+VALU peak).  AB_ONLY=cfg1,cfg4b,... restricts the run (profiling)."""
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import path_tracing_amd as hpt
 from path_tracing_amd import scene_io as S
-here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import bench
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ONLY = set(filter(None, os.environ.get("AB_ONLY", "").split(",")))
 out = {}
-def timed(fn, reps=3):
+
+
+def timed(scene, fn, reps=3):
     ms = []
     for _ in range(reps + 1):
-        fn(); ms.append(scene.stats()["ms_total"])
-    return float(np.median(ms[1:]))
-# config 1: cpu_bdpt estimator on input.txt, 256x256, 4 spp
-sc = S.load_scene(os.path.join(here, "tests/golden/scenes/input.txt"))
-L, sp, tr = S.flatten_for_pt(sc); order = S.object_order(sc)
-cam = S.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, 256, 256, tan_in_float=True)
-scene = hpt.Scene(L, sp, tr); scene.set_groups(*order)
-ms = timed(lambda: scene.render_bdpt(cam, 256, 256, 4, 4, 4, 8, hpt.make_params(seed=1)))
-out["cfg1_bdpt_input_256x256_4spp_spl8"] = {"ms": ms, "Msamples_per_s": 256 * 256 * 4 / ms / 1e3}
-scene.close()
-# config 2: PT, diffuse Cornell (36 triangles), 512x512, 64 spp
-L2, sp2, tr2 = S.cornell_diffuse()
-cam2 = S.make_camera(S.CORNELL_EYE, S.CORNELL_LOOK, S.CORNELL_UP, 50.0, 512, 512)
-scene = hpt.Scene(L2, sp2, tr2)
-ms = timed(lambda: scene.render_pt(cam2, 512, 512, 4, 64, hpt.make_params(seed=1)))
-out["cfg2_pt_cornell_diffuse_512x512_64spp"] = {"ms": ms, "Msamples_per_s": 512 * 512 * 64 / ms / 1e3}
-scene.close()
-# config 4: BDPT on mis_test.txt, 1024x1024, 64 spp
-sc4 = S.load_scene(os.path.join(here, "tests/golden/scenes/mis_test.txt"))
-L4, sp4, tr4 = S.flatten_for_pt(sc4); order4 = S.object_order(sc4)
-cam4 = S.make_camera(sc4.eye, sc4.look_at, sc4.view_up, sc4.fov, 1024, 1024, tan_in_float=True)
-scene = hpt.Scene(L4, sp4, tr4); scene.set_groups(*order4)
-ms = timed(lambda: scene.render_bdpt(cam4, 1024, 1024, 4, 4, 64, 8, hpt.make_params(seed=1)), reps=2)
-out["cfg4_bdpt_mis_test_1024x1024_64spp_spl8"] = {"ms": ms, "Msamples_per_s": 1024 * 1024 * 64 / ms / 1e3}
-# the same estimator on input.txt at config 4's size (a non-degenerate BDPT workload), 8 spp
-scene.close()
-cam1 = S.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, 1024, 1024, tan_in_float=True)
-scene = hpt.Scene(L, sp, tr); scene.set_groups(*order)
-ms = timed(lambda: scene.render_bdpt(cam1, 1024, 1024, 4, 4, 8, 8, hpt.make_params(seed=1)), reps=2)
-out["bdpt_input_1024x1024_8spp_spl8"] = {"ms": ms, "Msamples_per_s": 1024 * 1024 * 8 / ms / 1e3}
-scene.close()
-# config 5 shape on one GPU at reduced spp: 1M triangles, 4096x4096, 4 spp (PT)
-L5, sp5, tr5 = S.cornell_with_sphere(1_000_000)
-cam5 = S.make_camera(S.CORNELL_EYE, S.CORNELL_LOOK, S.CORNELL_UP, 50.0, 4096, 4096)
-scene = hpt.Scene(L5, sp5, tr5)
-st0 = scene.stats()
-ms = timed(lambda: scene.render_pt(cam5, 4096, 4096, 4, 4, hpt.make_params(seed=1)), reps=2)
-out["cfg5_pt_1Mtri_4096x4096_4spp_1gpu"] = {"ms": ms, "Msamples_per_s": 4096 * 4096 * 4 / ms / 1e3, "triangles": len(tr5),
-                                            "ms_bvh_build": st0["ms_bvh_build"], "bvh_depth": st0["bvh_depth"]}
-scene.close()
+        fn(hpt.FLAG_TIME_KERNELS)
+        st = scene.stats()
+        ms.append(st["ms_total"])
+    return float(np.median(ms[1:])), st
+
+
+def kernel_classes(st, bdpt):
+    if bdpt:
+        return {"extend_ms": st["ms_extend"], "vertex_ms": st["ms_shade"], "connect_ms": st["ms_connect"], "other_ms (light trace, reduce, resolve)": st["ms_other"]}
+    return {"trace_first_ms": st["ms_extend"] + st["ms_connect"], "trace_resume_ms": st["ms_resume"], "shade_ms": st["ms_shade"], "other_ms": st["ms_other"]}
+
+
+def pt_config(name, L, sp, tr, cam, W, H, spp, reps=3):
+    if ONLY and name not in ONLY:
+        return
+    with hpt.Scene(L, sp, tr) as scene:
+        st0 = scene.stats()
+        ms, st = timed(scene, lambda f: scene.render_pt(cam, W, H, 4, spp, hpt.make_params(seed=1, flags=f)), reps)
+        scene.render_pt(cam, W, H, 4, min(spp, 16), hpt.make_params(seed=1, flags=hpt.FLAG_COUNT_WORK))
+        wc = scene.stats()
+    k = spp / min(spp, 16)                       # the counting render traced min(spp, 16) samples per pixel
+    boxes = (wc["boxes_closest"] + wc["boxes_shadow"]) * k; tris = (wc["tris_closest"] + wc["tris_shadow"]) * k
+    rays = (wc["closest_rays"] + wc["shadow_rays"]) * k
+    trace_s = (st["ms_extend"] + st["ms_connect"] + st["ms_resume"]) * 1e-3
+    bytes_ = 32.0 * boxes / 2 + 36.0 * tris + 44.0 * wc["closest_rays"] * k + 36.0 * wc["shadow_rays"] * k
+    out[name] = {"ms": ms, "Msamples_per_s": W * H * spp / ms / 1e3, "triangles": len(tr), "kernels_last_render": kernel_classes(st, False),
+                 "rays_per_sample": rays / (W * H * spp), "nodes_per_ray": boxes / 2 / max(rays, 1), "tris_per_ray": tris / max(rays, 1),
+                 "bvh_depth": st0["bvh_depth"], "ms_bvh_build": st0["ms_bvh_build"],
+                 "roofline_trace_hbm": {"achieved_GBps": bytes_ / trace_s / 1e9, "peak_GBps": bench.HBM_PEAK_GBS, "frac": bytes_ / trace_s / 1e9 / bench.HBM_PEAK_GBS},
+                 "roofline_trace_valu": {"achieved_T_lane_ops": (bench.LANE_OPS_PER_BOX * boxes + bench.LANE_OPS_PER_TRI * tris) / trace_s / 1e12,
+                                         "peak_T_lane_ops": bench.VALU_PEAK_LANE_OPS / 1e12,
+                                         "frac": (bench.LANE_OPS_PER_BOX * boxes + bench.LANE_OPS_PER_TRI * tris) / trace_s / bench.VALU_PEAK_LANE_OPS}}
+
+
+def bdpt_config(name, scene_file, W, H, spp, spl, reps=2):
+    if ONLY and name not in ONLY:
+        return
+    sc = S.load_scene(os.path.join(HERE, "tests/golden/scenes", scene_file))
+    L, sp, tr = S.flatten_for_pt(sc)
+    cam = S.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, W, H, tan_in_float=True)
+    with hpt.Scene(L, sp, tr) as scene:
+        scene.set_groups(*S.object_order(sc))
+        ms, st = timed(scene, lambda f: scene.render_bdpt(cam, W, H, 4, 4, spp, spl, hpt.make_params(seed=1, flags=f)), reps)
+    n_lv = len(L) * spl * 4
+    out[name] = {"ms": ms, "Msamples_per_s": W * H * spp / ms / 1e3, "light_vertices": n_lv,
+                 "connections_per_s": W * H * spp * 4.0 * n_lv / ms / 1e3 if n_lv else None,
+                 "kernels_last_render": kernel_classes(st, True),
+                 "note": "connections_per_s counts every (eye vertex, light vertex) pair of up to 4 eye vertices per sample; "
+                         "the connect kernel is VALU-bound (profiles/: SQ pass), its table traffic is streamed by k_bdpt_reduce"}
+
+
+cam = lambda W, H: S.make_camera(S.CORNELL_EYE, S.CORNELL_LOOK, S.CORNELL_UP, 50.0, W, H)
+bdpt_config("cfg1_bdpt_input_256x256_4spp_spl8", "input.txt", 256, 256, 4, 8, reps=3)
+pt_config("cfg2_pt_cornell_diffuse_512x512_64spp", *S.cornell_diffuse(), cam(512, 512), 512, 512, 64)
+pt_config("cfg3_pt_100k_1024x1024_256spp", *S.cornell_with_sphere(100_000), cam(1024, 1024), 1024, 1024, 256)
+bdpt_config("cfg4_bdpt_mis_test_1024x1024_64spp_spl8", "mis_test.txt", 1024, 1024, 64, 8)
+bdpt_config("cfg4b_bdpt_input_1024x1024_8spp_spl8", "input.txt", 1024, 1024, 8, 8)
+pt_config("cfg5_pt_1Mtri_4096x4096_4spp_1gpu", *S.cornell_with_sphere(1_000_000), cam(4096, 4096), 4096, 4096, 4, reps=2)
 print(json.dumps(out, indent=1))
