@@ -123,8 +123,14 @@ int64_t hpt_local_pixels(int W, int H, const hpt_params *params);
 int hpt_render_pt(hpt_scene *scene, const void *camera, int W, int H,
                   int eye_depth, int spp, const hpt_params *params, float *host_image);
 
-/* Asynchronous render of this rank's tiles into device memory:
- * d_local holds hpt_local_pixels() float3 records in local tile order. */
+/* Render of this rank's tiles into device memory: d_local holds hpt_local_pixels() float3 records in local
+ * tile order.  Everything is enqueued on hip_stream (plus one stream of the scene, joined back before the
+ * call returns); the result is complete when the stream reaches the end of what the call enqueued.  The call
+ * returns without waiting for the device as long as no path outlives eye_depth iterations; paths kept alive by
+ * free delta bounces (mirror, glass: reference src/pt_cu.cu:228) need further iterations whose number only the
+ * device knows, and for those the calling thread waits on a 4-byte read-back every other iteration -- i.e. on
+ * scenes with delta materials the call MAY BLOCK THE HOST for most of the render's duration.  It never blocks
+ * the device: both pipelines of a render keep running while the host waits. */
 int hpt_render_pt_device(hpt_scene *scene, const void *camera, int W, int H,
                          int eye_depth, int spp, const hpt_params *params,
                          void *d_local, void *hip_stream);

@@ -418,7 +418,7 @@ constexpr int kVtxTargetGroups = 1024;
 __global__ __launch_bounds__(kBlock)
 void k_bdpt_vertex(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const uint32_t *queue, const uint32_t *qcount,
                    uint32_t *next_queue, uint32_t *next_count, uint32_t *cqueue, uint32_t *ccount,
-                   int eye_depth, int max_delta, uint32_t slots){
+                   int eye_depth, int max_delta, uint32_t slots, float ex, float ey, float ez){
     __shared__ uint32_t s_next[kVtxChunk];
     __shared__ uint32_t s_conn[kVtxChunk];
     __shared__ uint32_t s_cnt[4];
@@ -468,6 +468,27 @@ void k_bdpt_vertex(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const uint32_t *
                     bp.vtx_wo[path] = make_float4(wo.x, wo.y, wo.z, u2f((uint32_t) depth));
                     bp.hist_pos_eta[(size_t) depth * slots + path] = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, hit.m.eta);
                     bp.vtx_base[path] = make_float4(hit.m.base.x, hit.m.base.y, hit.m.base.z, 0.0f);
+                    {   // shading contexts of this vertex for the connection kernel: what every one of its connections
+                        // would otherwise rebuild (cpu_bdpt.cpp:401 evaluates the BSDF with the vertex normal,
+                        // cpu_calculate_mis_weight :119-131 with the re-normalised one and the direction to the previous vertex)
+                        const float alpha = roughness_to_alpha(hit.m.roughness);
+                        ShadeCtx ce = make_shade_ctx(hit.normal, wo);
+                        float lam_e = ggx_lambda(ce.wo, alpha);
+                        f3 diffuse = hit.m.base / kPi * (1.0f - hit.m.metallic);
+                        f3 ns = normalize3(hit.normal);
+                        f3 wo_s_w = (depth == 0) ? normalize3(mk3(ex, ey, ez) - hit.pos)
+                                                 : normalize3(xyz(bp.hist_pos_eta[(size_t) (depth - 1) * slots + path]) - hit.pos);
+                        ShadeCtx cs = make_shade_ctx(ns, wo_s_w);
+                        float lam_s = ggx_lambda(cs.wo, alpha);
+                        float4 *e = bp.ectx + path;
+                        e[0 * (size_t) slots] = make_float4(ce.T.x, ce.T.y, ce.T.z, ce.B.x);
+                        e[1 * (size_t) slots] = make_float4(ce.B.y, ce.B.z, ce.wo.x, ce.wo.y);
+                        e[2 * (size_t) slots] = make_float4(ce.wo.z, lam_e, diffuse.x, diffuse.y);
+                        e[3 * (size_t) slots] = make_float4(diffuse.z, ns.x, ns.y, ns.z);
+                        e[4 * (size_t) slots] = make_float4(cs.T.x, cs.T.y, cs.T.z, cs.B.x);
+                        e[5 * (size_t) slots] = make_float4(cs.B.y, cs.B.z, cs.wo.x, cs.wo.y);
+                        e[6 * (size_t) slots] = make_float4(cs.wo.z, lam_s, 0.0f, 0.0f);
+                    }
 
                     uint2 r2 = pb.rng[path];
                     uint64_t rs = ((uint64_t) r2.y << 32) | (uint64_t) r2.x;
@@ -529,21 +550,70 @@ HPT_DEV Mat lv_mat(const LightVertexDev &lv){
     return m;
 }
 
+// per light vertex, once per render: see LightVertexCtx
+__global__ __launch_bounds__(kBlock)
+void k_bdpt_light_ctx(const LightVertexDev *lvs, LightVertexCtx *out, int n_lv, int light_depth){
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if(j >= n_lv) return;
+    const LightVertexDev lv = lvs[j];
+    const int t_idx = j % light_depth;
+    const Mat m = lv_mat(lv);
+    const float alpha = roughness_to_alpha(m.roughness);
+    f3 N = ld3(lv.normal), pos = ld3(lv.pos);
+    f3 to_prev = t_idx > 0 ? normalize3(ld3(lvs[j - 1].pos) - pos) : mk3(0, 0, 0);
+    ShadeCtx cl = make_shade_ctx(N, to_prev);
+    f3 nt = normalize3(N);
+    f3 wo_t_w = (t_idx == 0) ? normalize3(N) : to_prev;
+    ShadeCtx ct = make_shade_ctx(nt, wo_t_w);
+    LightVertexCtx c;
+    c.T[0] = cl.T.x; c.T[1] = cl.T.y; c.T[2] = cl.T.z; c.B[0] = cl.B.x; c.B[1] = cl.B.y; c.B[2] = cl.B.z;
+    c.wo_l[0] = cl.wo.x; c.wo_l[1] = cl.wo.y; c.wo_l[2] = cl.wo.z;
+    c.nt[0] = nt.x; c.nt[1] = nt.y; c.nt[2] = nt.z;
+    c.Tn[0] = ct.T.x; c.Tn[1] = ct.T.y; c.Tn[2] = ct.T.z; c.Bn[0] = ct.B.x; c.Bn[1] = ct.B.y; c.Bn[2] = ct.B.z;
+    c.wo_t[0] = ct.wo.x; c.wo_t[1] = ct.wo.y; c.wo_t[2] = ct.wo.z;
+    c.lam_l = ggx_lambda(cl.wo, alpha); c.lam_t = ggx_lambda(ct.wo, alpha);
+    f3 diffuse = m.base / kPi * (1.0f - m.metallic);
+    c.diffuse[0] = diffuse.x; c.diffuse[1] = diffuse.y; c.diffuse[2] = diffuse.z;
+    c.pad[0] = c.pad[1] = 0.0f;
+    out[j] = c;
+}
+
+// the two shading contexts of an eye vertex as k_bdpt_vertex stored them; each is loaded where it is used (loading
+// both up front costs the connection kernel a wave of occupancy: 133 instead of 114 VGPRs)
+HPT_DEV void load_eye_value_ctx(const BdptPathBuf &bp, uint32_t path, uint32_t slots, f3 v_n, ShadeCtx &c, ShadePre &pre){
+    const float4 *p = bp.ectx + path;
+    float4 a = p[0], b = p[(size_t) slots], d = p[2 * (size_t) slots], e = p[3 * (size_t) slots];
+    c.T = mk3(a.x, a.y, a.z); c.B = mk3(a.w, b.x, b.y); c.N = v_n; c.wo = mk3(b.z, b.w, d.x);
+    pre.lam_o = d.y; pre.diffuse = mk3(d.z, d.w, e.x);
+}
+HPT_DEV void load_eye_mis_ctx(const BdptPathBuf &bp, uint32_t path, uint32_t slots, ShadeCtx &c, ShadePre &pre){
+    const float4 *p = bp.ectx + path;
+    float4 d = p[3 * (size_t) slots], e = p[4 * (size_t) slots], f = p[5 * (size_t) slots], g = p[6 * (size_t) slots];
+    c.N = mk3(d.y, d.z, d.w); c.T = mk3(e.x, e.y, e.z); c.B = mk3(e.w, f.x, f.y); c.wo = mk3(f.z, f.w, g.x);
+    pre.lam_o = g.y; pre.diffuse = mk3(0, 0, 0);          // the pdf does not use the diffuse lobe
+}
+
 // cpu_calculate_mis_weight, src/cpu_bdpt.cpp:112-167.  The current eye vertex still carries the
 // placeholder pdfs (0, 1) when the CPU connects it (cpu_bdpt.cpp:385); earlier ones their final values.
-HPT_DEV float bd_mis_weight(const BdptPathBuf &bp, uint32_t path, uint32_t slots, int s_idx, f3 ev_pos, f3 ev_normal, const Mat &ev_m,
-                            const LightVertexDev *light_path, int t_idx, f3 dir_e_to_l, float dist2, f3 camera_pos){
+// The two solid-angle pdfs are evaluated in the per-vertex contexts (re-normalised normals, directions to the
+// previous vertices) that k_bdpt_vertex / k_bdpt_light_ctx prepared.
+HPT_DEV float bd_mis_weight(const BdptPathBuf &bp, uint32_t path, uint32_t slots, int s_idx, const Mat &ev_m,
+                            const LightVertexDev *light_path, const LightVertexCtx *lcp, int t_idx, f3 dir_e_to_l, float dist2){
     const LightVertexDev &lv = light_path[t_idx];
-    f3 ns = normalize3(ev_normal);
-    f3 nt = normalize3(ld3(lv.normal));
+    ShadeCtx cs; ShadePre ps;
+    load_eye_mis_ctx(bp, path, slots, cs, ps);
+    f3 ns = cs.N;
+    f3 nt = ld3(lcp->nt);
     float cos_s = fmaxf(0.0f, dot3(ns, dir_e_to_l));
     float cos_t = fmaxf(0.0f, dot3(nt, dir_e_to_l * -1.0f));
     if(cos_s <= 0.0f || cos_t <= 0.0f || dist2 < 1e-6f) return 0.0f;
-    f3 wo_s = (s_idx == 0) ? normalize3(camera_pos - ev_pos)
-                           : normalize3(xyz(bp.hist_pos_eta[(size_t) (s_idx - 1) * slots + path]) - ev_pos);
-    f3 wo_t = (t_idx == 0) ? normalize3(ld3(lv.normal)) : normalize3(ld3(light_path[t_idx - 1].pos) - ld3(lv.pos));
-    float pdf_omega_s = fmaxf(bsdf_pdf_only(ev_m, wo_s, dir_e_to_l, ns), 1e-6f);
-    float pdf_omega_t = fmaxf(bsdf_pdf_only(lv_mat(lv), wo_t, dir_e_to_l * -1.0f, nt), 1e-6f);
+    f3 unused; float p_s, p_t;
+    bsdf_eval_pdf<false, true>(ev_m, cs, dir_e_to_l, unused, p_s, &ps);
+    ShadeCtx ct; ct.T = ld3(lcp->Tn); ct.B = ld3(lcp->Bn); ct.N = nt; ct.wo = ld3(lcp->wo_t);
+    ShadePre pt; pt.lam_o = lcp->lam_t; pt.diffuse = mk3(0, 0, 0);
+    bsdf_eval_pdf<false, true>(lv_mat(lv), ct, dir_e_to_l * -1.0f, unused, p_t, &pt);
+    float pdf_omega_s = fmaxf(p_s, 1e-6f);
+    float pdf_omega_t = fmaxf(p_t, 1e-6f);
     float pdf_s_to_t = pdf_omega_s * cos_t / dist2;
     float pdf_t_to_s = pdf_omega_t * cos_s / dist2;
     float sum_ratios = 1.0f;
@@ -583,10 +653,11 @@ HPT_DEV float bd_mis_weight(const BdptPathBuf &bp, uint32_t path, uint32_t slots
 // tiles = 256 candidate pairs.  Phase 1: every lane runs the cheap culls of its pair (zero throughput,
 // distance, both cosines, emission cone) and the survivors are compacted into an LDS list (ballot +
 // mbcnt); culled pairs get their zero written at once.  Phase 2: the expensive part -- two BSDF values,
-// the shadow ray, the MIS weight -- runs over the dense survivor list, so its lanes are all busy.
+// the shadow ray, the MIS weight -- runs over the dense survivor list, so its lanes are all busy.  Frames,
+// local directions, Lambda terms and diffuse lobes come from the per-vertex contexts.
 __global__ __launch_bounds__(kBlock)
-void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lvs, int n_lv, int light_depth,
-                    const uint32_t *cqueue, const uint32_t *ccount, float ex, float ey, float ez, uint32_t slots){
+void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lvs, const LightVertexCtx *lctx, int n_lv,
+                    int light_depth, const uint32_t *cqueue, const uint32_t *ccount, uint32_t slots){
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     __shared__ uint32_t s_pair_path[kBlock];
     __shared__ uint32_t s_pair_j[kBlock];
@@ -596,7 +667,6 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
     uint32_t chunks = ((uint32_t) n_lv + 63u) / 64u;
     unsigned long long items = (unsigned long long) count * chunks;
     uint32_t wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    f3 cam_eye = mk3(ex, ey, ez);
     unsigned long long groups = (items + 3ull) / 4ull;
     for(unsigned long long gidx = blockIdx.x; gidx < groups; gidx += gridDim.x){
         if(threadIdx.x == 0) s_n = 0u;
@@ -641,7 +711,8 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
             path = s_pair_path[threadIdx.x]; j = (int) s_pair_j[threadIdx.x];
             float4 vp = bp.vtx_pos[path], vn = bp.vtx_nrm[path], vt = bp.vtx_thr[path], vw = bp.vtx_wo[path], vb = bp.vtx_base[path];
             const LightVertexDev lv = lvs[j];
-            f3 v_pos = xyz(vp), v_n = xyz(vn), v_thr = xyz(vt), wo_e = xyz(vw);
+            const LightVertexCtx *lcp = lctx + j;
+            f3 v_pos = xyz(vp), v_n = xyz(vn), v_thr = xyz(vt);
             Mat vm; vm.base = xyz(vb); vm.roughness = vp.w; vm.metallic = vn.w; vm.eta = vt.w;
             int depth = (int) f2u(vw.w);
             f3 lthr = ld3(lv.thr);
@@ -653,18 +724,21 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
             float cosL = fmaxf(0.0f, dot3(ld3(lv.normal), wi * -1.0f));
             int t_idx = j % light_depth;
             f3 contrib = mk3(0, 0, 0);
-            f3 fE = bsdf_value(vm, wo_e, wi, v_n);
+            f3 fE; float pdf_unused;
+            { ShadeCtx ce; ShadePre pe;
+              load_eye_value_ctx(bp, path, slots, v_n, ce, pe);
+              bsdf_eval_pdf<true, false>(vm, ce, wi, fE, pdf_unused, &pe); }
             f3 fL = mk3(1.0f, 1.0f, 1.0f);
             if(!(lv.flags & 1u) && t_idx > 0){
-                f3 prev = ld3(lvs[j - 1].pos);
-                f3 wo_l = normalize3(prev - ld3(lv.pos));
-                fL = bsdf_value(lv_mat(lv), wo_l, wi * -1.0f, ld3(lv.normal));
+                ShadeCtx cl; cl.T = ld3(lcp->T); cl.B = ld3(lcp->B); cl.N = ld3(lv.normal); cl.wo = ld3(lcp->wo_l);
+                ShadePre pl; pl.lam_o = lcp->lam_l; pl.diffuse = ld3(lcp->diffuse);
+                bsdf_eval_pdf<true, false>(lv_mat(lv), cl, wi * -1.0f, fL, pdf_unused, &pl);
             }
             bool ok = !((fE.x <= 0.0f && fE.y <= 0.0f && fE.z <= 0.0f) || (fL.x <= 0.0f && fL.y <= 0.0f && fL.z <= 0.0f));
             if(ok && bd_visible(sc, v_pos + v_n * kEps, ld3(lv.pos) + ld3(lv.normal) * kEps, stk)){
                 float G = (cosE * cosL) / fmaxf(dist2, 1e-4f);
-                const LightVertexDev *lp_base = lvs + (size_t) (j / light_depth) * light_depth;
-                float mis_w = bd_mis_weight(bp, path, slots, depth, v_pos, v_n, vm, lp_base, t_idx, d_vec, dist2, cam_eye);
+                const size_t first = (size_t) (j / light_depth) * light_depth;
+                float mis_w = bd_mis_weight(bp, path, slots, depth, vm, lvs + first, lcp, t_idx, d_vec, dist2);
                 f3 c = v_thr * fE * G * fL * lthr * mk3(1.0f, 1.0f, 1.0f) * mis_w;
                 if(is_valid_color(c)) contrib = clamp_radiance(c, 15.0f);
             }
@@ -738,23 +812,27 @@ void launch_bdpt_extend(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, const
 }
 void launch_bdpt_vertex(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptPathBuf bp, const uint32_t *queue,
                         const uint32_t *qcount, uint32_t max_items, uint32_t *next_queue, uint32_t *next_count,
-                        uint32_t *cqueue, uint32_t *ccount, int eye_depth, int max_delta, uint32_t slots){
+                        uint32_t *cqueue, uint32_t *ccount, int eye_depth, int max_delta, uint32_t slots, const float eye[3]){
     uint32_t g = (max_items + kVtxChunk - 1) / kVtxChunk;
     if(g < (uint32_t) kVtxTargetGroups) g = (uint32_t) kVtxTargetGroups;
     uint32_t small = (max_items + kBlock - 1) / kBlock;
     if(small < g) g = small < 1u ? 1u : small;
     hipLaunchKernelGGL(k_bdpt_vertex, dim3(g), dim3(kBlock), 0, s, sc, pb, bp, queue, qcount, next_queue, next_count, cqueue,
-                       ccount, eye_depth, max_delta, slots);
+                       ccount, eye_depth, max_delta, slots, eye[0], eye[1], eye[2]);
+}
+void launch_bdpt_light_ctx(hipStream_t s, const LightVertexDev *lv, LightVertexCtx *ctx, int n_lv, int light_depth){
+    if(n_lv <= 0) return;
+    hipLaunchKernelGGL(k_bdpt_light_ctx, dim3((n_lv + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lv, ctx, n_lv, light_depth);
 }
 void launch_bdpt_connect(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lv,
-                         int n_lv, int light_depth, const uint32_t *cqueue, const uint32_t *ccount, uint32_t max_items,
-                         const float eye[3], uint32_t slots){
+                         const LightVertexCtx *lctx, int n_lv, int light_depth, const uint32_t *cqueue, const uint32_t *ccount,
+                         uint32_t max_items, uint32_t slots){
     unsigned long long waves = (unsigned long long) max_items * (((unsigned) n_lv + 63u) / 64u);
     unsigned long long g = (waves + (kBlock / 64) - 1) / (kBlock / 64);
     if(g < 1ull) g = 1ull;
     if(g > 16384ull) g = 16384ull;
-    hipLaunchKernelGGL(k_bdpt_connect, dim3((uint32_t) g), dim3(kBlock), 0, s, sc, pb, bp, lv, n_lv, light_depth, cqueue, ccount,
-                       eye[0], eye[1], eye[2], slots);
+    hipLaunchKernelGGL(k_bdpt_connect, dim3((uint32_t) g), dim3(kBlock), 0, s, sc, pb, bp, lv, lctx, n_lv, light_depth, cqueue, ccount,
+                       slots);
 }
 void launch_bdpt_reduce(hipStream_t s, PathBuf pb, BdptPathBuf bp, int n_lv, const uint32_t *cqueue, const uint32_t *ccount,
                         uint32_t max_items){

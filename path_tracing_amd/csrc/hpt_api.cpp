@@ -109,6 +109,7 @@ struct hpt_scene {
     DevMaterial *bd_mats = nullptr; DevLight *bd_lights = nullptr;
     BdptPathBuf bp{}; size_t bd_cap_slots = 0, bd_cap_hist = 0, bd_cap_contrib = 0;
     LightVertexDev *d_lv = nullptr; size_t bd_cap_lv = 0;
+    LightVertexCtx *d_lctx = nullptr; size_t bd_cap_lctx = 0;
     uint32_t *cqueue = nullptr; size_t bd_cap_cqueue = 0;
 
     hipEvent_t ev_start = nullptr, ev_stop = nullptr; bool ev_valid = false;
@@ -378,18 +379,30 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         } else q.pending_shadow = it;
         q.cur ^= 1;
     };
-    // iterations past eye_depth: only free delta bounces can keep a path alive this long: look before
-    // launching, every other iteration (an empty launch costs less than a read-back)
-    auto tail = [&](Pass &q) -> int {
-        for(int it = eye_depth; it < max_iters; ++it){
-            if(((it - eye_depth) & 1) == 0){
-                HIP_TRY(hipMemcpyAsync(q.h_count, &q.qcnt[it], sizeof(uint32_t), hipMemcpyDeviceToHost, q.st));
-                HIP_TRY(hipStreamSynchronize(q.st));
-                if(*q.h_count == 0u) break;
+    // Iterations past eye_depth: only paths that took free delta bounces are still alive (reference src/pt_cu.cu:228),
+    // and how many more iterations they need is known on the device only.  The host looks before it launches, every
+    // other iteration (an empty launch costs less than a read-back): the counter of each pipeline in flight is read
+    // back on that pipeline's stream FIRST, then the host waits for one after the other, so the pipelines keep running
+    // side by side while it does.  This is the one place where hpt_render_pt_device blocks the calling thread
+    // (include/hpt.h); a scene without delta materials never gets here with a non-empty queue and pays one read-back.
+    auto tails = [&](int npipes) -> int {
+        bool live[2] = { npipes > 0, npipes > 1 };
+        for(int it = eye_depth; it < max_iters && (live[0] || live[1]); ++it){
+            const bool look = ((it - eye_depth) & 1) == 0;
+            if(look) for(int k = 0; k < npipes; ++k) if(live[k])
+                HIP_TRY(hipMemcpyAsync(pipe[k].h_count, &pipe[k].qcnt[it], sizeof(uint32_t), hipMemcpyDeviceToHost, pipe[k].st));
+            for(int k = 0; k < npipes; ++k){
+                if(!live[k]) continue;
+                if(look){
+                    HIP_TRY(hipStreamSynchronize(pipe[k].st));
+                    if(*pipe[k].h_count == 0u){ live[k] = false; continue; }
+                }
+                iteration(pipe[k], it);
             }
-            iteration(q, it);
         }
-        if(q.pending_shadow >= 0){
+        for(int k = 0; k < npipes; ++k){
+            Pass &q = pipe[k];
+            if(q.pending_shadow < 0) continue;
             TraceSplit split{ q.lqueue[0], &q.lecnt[max_iters], q.lqueue[1], &q.lscnt[max_iters], budget };
             { LaunchTimer t(s, q.st, timek, 2);
               launch_trace(q.st, s->sd, q.pb, q.sb, nullptr, nullptr, 0, q.squeue, &q.scnt[q.pending_shadow], q.slots,
@@ -416,8 +429,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
             iteration(pipe[0], it);
             if(second) iteration(pipe[1], it);
         }
-        rc = tail(pipe[0]); if(rc) return rc;
-        if(second){ rc = tail(pipe[1]); if(rc) return rc; }
+        rc = tails(second ? 2 : 1); if(rc) return rc;
         // the per-pixel sums are added in sample order: this pass, then the other pipeline's
         { LaunchTimer t(s, stream, timek, 3);
           launch_resolve(stream, tl, pipe[0].pb, s->accum, pipe[0].sthis); }
@@ -502,9 +514,10 @@ void free_bdpt(hpt_scene *s){
     free_bdpt_scene(s);
     hipFree(s->bp.last_pos_pdf); hipFree(s->bp.last_normal); hipFree(s->bp.vtx_pos); hipFree(s->bp.vtx_nrm); hipFree(s->bp.vtx_thr);
     hipFree(s->bp.vtx_wo); hipFree(s->bp.vtx_base); hipFree(s->bp.hist_pos_eta); hipFree(s->bp.hist_pdf); hipFree(s->bp.contrib);
-    hipFree(s->d_lv); hipFree(s->cqueue);
-    s->bp = BdptPathBuf{}; s->d_lv = nullptr; s->cqueue = nullptr;
-    s->bd_cap_slots = s->bd_cap_hist = s->bd_cap_contrib = s->bd_cap_lv = s->bd_cap_cqueue = 0;
+    hipFree(s->bp.ectx);
+    hipFree(s->d_lv); hipFree(s->d_lctx); hipFree(s->cqueue);
+    s->bp = BdptPathBuf{}; s->d_lv = nullptr; s->d_lctx = nullptr; s->cqueue = nullptr;
+    s->bd_cap_slots = s->bd_cap_hist = s->bd_cap_contrib = s->bd_cap_lv = s->bd_cap_lctx = s->bd_cap_cqueue = 0;
 }
 
 int ensure_bdpt_scene(hpt_scene *s){
@@ -590,6 +603,7 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
         c = s->bd_cap_slots; rc = grow(&s->bp.vtx_thr, c, slots); if(rc) return rc;
         c = s->bd_cap_slots; rc = grow(&s->bp.vtx_wo, c, slots); if(rc) return rc;
         c = s->bd_cap_slots; rc = grow(&s->bp.vtx_base, c, slots); if(rc) return rc;
+        c = s->bd_cap_slots * 7; rc = grow(&s->bp.ectx, c, slots * 7); if(rc) return rc;
         s->bd_cap_slots = slots;
         s->bd_cap_hist = 0; s->bd_cap_contrib = 0;
     }
@@ -603,6 +617,7 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
       } }
     rc = grow(&s->bp.contrib, s->bd_cap_contrib, slots * (size_t) std::max(n_lv, 1)); if(rc) return rc;
     rc = grow(&s->d_lv, s->bd_cap_lv, (size_t) std::max(n_lv, 1)); if(rc) return rc;
+    rc = grow(&s->d_lctx, s->bd_cap_lctx, (size_t) std::max(n_lv, 1)); if(rc) return rc;
 
     const float *cf = (const float *) camera;
     CameraDev cam;
@@ -617,7 +632,8 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     if(s->nl > 0){                                       // no lights: the CPU renderer returns at once (cpu_bdpt.cpp:178)
         { LaunchTimer t(s, stream, timek, 3);
-          launch_bdpt_light_trace(stream, s->bd, s->d_lv, total_light_paths, light_depth, spl, P.seed, P.max_delta); }
+          launch_bdpt_light_trace(stream, s->bd, s->d_lv, total_light_paths, light_depth, spl, P.seed, P.max_delta);
+          launch_bdpt_light_ctx(stream, s->d_lv, s->d_lctx, n_lv, light_depth); }
         for(int done = 0; done < spp; done += spass){
             int sthis = std::min(spass, spp - done);
             uint32_t nslots = (uint32_t) tl.n_local * (uint32_t) sthis;
@@ -638,10 +654,10 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
                   launch_bdpt_extend(stream, s->bd, s->pass[0].pb, eq, &qcnt[ci], nslots); }
                 { LaunchTimer t(s, stream, timek, 1);
                   launch_bdpt_vertex(stream, s->bd, s->pass[0].pb, s->bp, eq, &qcnt[ci], nslots, s->pass[0].queue[cur ^ 1], &qcnt[ci + 1],
-                                     s->cqueue, &ccnt[ci], eye_depth, P.max_delta, (uint32_t) slots); }
+                                     s->cqueue, &ccnt[ci], eye_depth, P.max_delta, (uint32_t) slots, cam.eye); }
                 { LaunchTimer t(s, stream, timek, 2);
-                  launch_bdpt_connect(stream, s->bd, s->pass[0].pb, s->bp, s->d_lv, n_lv, light_depth, s->cqueue, &ccnt[ci], nslots,
-                                      cam.eye, (uint32_t) slots); }
+                  launch_bdpt_connect(stream, s->bd, s->pass[0].pb, s->bp, s->d_lv, s->d_lctx, n_lv, light_depth, s->cqueue, &ccnt[ci], nslots,
+                                      (uint32_t) slots); }
                 { LaunchTimer t(s, stream, timek, 3);
                   launch_bdpt_reduce(stream, s->pass[0].pb, s->bp, n_lv, s->cqueue, &ccnt[ci], nslots); }
                 cur ^= 1;
