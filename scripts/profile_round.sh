@@ -28,3 +28,7 @@ pmc WRITE_SIZE WRITE_SIZE
 pmc TCC TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pmc SQ SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE
 pmc SQ2 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD
+# texture-addresser counters: at most two per pass (a longer list in one pass is refused with "error code 38: Request
+# exceeds the capabilities of the hardware to collect" -- round 1 mistook that for a crash)
+pmc TA1 TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum
+pmc TA2 TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum

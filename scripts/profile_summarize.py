@@ -16,7 +16,7 @@ def kname(n):
         if k in n: return k
     return None
 out = collections.defaultdict(dict)
-for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ", "SQ2"):
+for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ", "SQ2", "TA1", "TA2"):
     fs = glob.glob(os.path.join(src, "pmc_" + c, "*", "*_counter_collection.csv"))
     if not fs: continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
