@@ -48,6 +48,8 @@ for k, a in out.items():
         d["valu_wave_insts"] = a["SQ_INSTS_VALU"]; d["salu_insts"] = a.get("SQ_INSTS_SALU"); d["gpu_cycles"] = cycles
         d["valu_utilization"] = a["SQ_INSTS_VALU"] / (cycles * 256.0)
         if a.get("SQ_THREAD_CYCLES_VALU"): d["valu_active_lanes_avg"] = a["SQ_THREAD_CYCLES_VALU"] / a["SQ_INSTS_VALU"]
+    extra = {cn: v for cn, v in a.items() if cn.startswith(("TA_", "SQ_WAVE", "SQ_BUSY", "SQ_ACTIVE", "SQ_WAIT", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_VMEM"))}
+    if extra: d["other_counters"] = extra
     res["kernels"][k] = d
 kf, kr = res["kernels"].get("k_trace_first"), res["kernels"].get("k_trace_resume")
 if kf and kf.get("hbm_bytes_per_launch") is not None:
