@@ -325,7 +325,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     // one pass in flight on one pipeline
     struct Pass {
         PathBuf pb; ShadowBuf sb; uint32_t *queue[2], *squeue, *lqueue[2]; uint32_t *counters, *h_count; hipStream_t st;
-        int sthis = 0, cur = 0, pending_shadow = -1; uint32_t slots = 0;
+        int sthis = 0, cur = 0, pending_shadow = -1; uint32_t slots = 0; PrimaryGen primary{};
         uint32_t *qcnt = nullptr, *scnt = nullptr, *lecnt = nullptr, *lscnt = nullptr;
     };
     Pass pipe[2]{};
@@ -344,17 +344,27 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         q.lscnt = q.counters + 3 * (max_iters + 2);       // iteration i set aside for its second launch
     }
 
+    // Iteration 0 needs no generate launch: its trace and shade kernels recompute the camera ray of a slot from the slot
+    // number (PRIMARY variants; -3 % per render: the launch and the 72 B per path it writes and iteration 0 reads back).
+    // The counting and the scan variants keep the stored form.
+    const bool in_flight_primaries = !count && !legacy && !((flags >> 17) & 1);      // flags bits 16-31: development switches
     auto begin_pass = [&](Pass &q, int done) -> int {
         q.sthis = std::min(spass, spp - done);
         q.slots = (uint32_t) tl.n_local * (uint32_t) q.sthis;
         q.cur = 0; q.pending_shadow = -1;
         HIP_TRY(hipMemsetAsync(q.counters, 0, (size_t) n_counters * sizeof(uint32_t), q.st));
-        LaunchTimer t(s, q.st, timek, 3);
-        launch_generate(q.st, tl, cam, q.pb, &q.qcnt[0], q.sthis, (uint32_t) (P.sample_offset + done), P.seed, wc);
+        q.primary.tl = tl; q.primary.cam = cam; q.primary.first_sample = (uint32_t) (P.sample_offset + done); q.primary.pad = 0u; q.primary.seed = P.seed;
+        if(in_flight_primaries){
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) &q.qcnt[0], (int) q.slots, 1, q.st));
+        } else {
+            LaunchTimer t(s, q.st, timek, 3);
+            launch_generate(q.st, tl, cam, q.pb, &q.qcnt[0], q.sthis, q.primary.first_sample, P.seed, wc);
+        }
         return HPT_OK;
     };
     auto iteration = [&](Pass &q, int it){
         const uint32_t *eq = it == 0 ? nullptr : q.queue[q.cur];
+        const PrimaryGen *primary = (it == 0 && in_flight_primaries) ? &q.primary : nullptr;
         if(legacy){
             LaunchTimer t(s, q.st, timek, 0);
             launch_extend(q.st, s->sd, q.pb, eq, &q.qcnt[it], q.slots, kflags, wc);
@@ -363,16 +373,16 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
             TraceSplit split{ q.lqueue[0], &q.lecnt[it], q.lqueue[1], &q.lscnt[it], budget };
             { LaunchTimer t(s, q.st, timek, 0);
               launch_trace(q.st, s->sd, q.pb, q.sb, eq, &q.qcnt[it], q.slots, q.squeue,
-                           q.pending_shadow >= 0 ? &q.scnt[q.pending_shadow] : nullptr, q.slots, s->stack_levels, kflags, tuning, wc, &split); }
+                           q.pending_shadow >= 0 ? &q.scnt[q.pending_shadow] : nullptr, q.slots, s->stack_levels, kflags, tuning, wc, &split, primary); }
             if(split.budget > 0){
                 LaunchTimer t(s, q.st, timek, 4);
-                launch_trace_resume(q.st, s->sd, q.pb, q.sb, true, q.pending_shadow >= 0, q.slots, s->stack_levels, wc, split);
+                launch_trace_resume(q.st, s->sd, q.pb, q.sb, true, q.pending_shadow >= 0, q.slots, s->stack_levels, wc, split, primary);
             }
             q.pending_shadow = -1;
         }
         { LaunchTimer t(s, q.st, timek, 1);
           launch_shade(q.st, s->sd, q.pb, eq, &q.qcnt[it], q.slots, q.queue[q.cur ^ 1],
-                       &q.qcnt[it + 1], q.sb, q.squeue, &q.scnt[it], eye_depth, P.max_delta, roulette, wc); }
+                       &q.qcnt[it + 1], q.sb, q.squeue, &q.scnt[it], eye_depth, P.max_delta, roulette, wc, primary); }
         if(legacy){
             LaunchTimer t(s, q.st, timek, 2);
             launch_connect(q.st, s->sd, q.pb, q.sb, q.squeue, &q.scnt[it], q.slots, kflags, wc);

@@ -44,6 +44,10 @@ struct Tiling {
 
 struct CameraDev { float eye[3], UL[3], dx[3], dy[3]; };
 
+// What it takes to recompute the primary ray of a path slot (reference src/pt_cu.cu:36-46): handed to the PRIMARY
+// variants of k_trace / k_shade, which run iteration 0 of a pass without a generate launch.
+struct PrimaryGen { Tiling tl; CameraDev cam; uint32_t first_sample; uint32_t pad; uint64_t seed; };
+
 struct WorkCounters {    // device counters, COUNT_WORK only
     unsigned long long boxes_closest, tris_closest, boxes_shadow, tris_shadow, closest_rays, shadow_rays, path_iters, samples,
                        lane_steps_closest, wave_steps_closest, lane_steps_shadow, wave_steps_shadow,
@@ -71,7 +75,7 @@ void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t
                    uint32_t max_items, int flags, WorkCounters *wc);
 void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
                   uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue,
-                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc);
+                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc, const PrimaryGen *primary = nullptr);
 void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,
                     const uint32_t *scount, uint32_t max_items, int flags, WorkCounters *wc);
 // merged closest-hit (equeue) + any-hit (squeue) launch; either queue may be absent (null count)
@@ -81,9 +85,10 @@ struct TraceSplit { uint32_t *equeue, *ecount, *squeue, *scount; int budget; };
 void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue,
                   const uint32_t *ecount, uint32_t max_extend, const uint32_t *squeue, const uint32_t *scount,
                   uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc,
-                  const TraceSplit *split = nullptr);
+                  const TraceSplit *split = nullptr, const PrimaryGen *primary = nullptr);
 void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
-                         uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split);
+                         uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split,
+                         const PrimaryGen *primary = nullptr);
 // fills frames[4 * num_tris] from tris (once per scene)
 void launch_tri_frames(hipStream_t s, const float4 *tris, int num_tris, float4 *frames);
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass);

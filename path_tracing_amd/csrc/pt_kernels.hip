@@ -216,6 +216,24 @@ HPT_DEV void flush_tally(const Tally &tally, uint32_t rays, WorkCounters *wc, bo
 
 // ---- kernels ----------------------------------------------------------------------------
 
+// The primary ray of path slot i (reference src/pt_cu.cu:36-46): sample j = i / n_local of local pixel i % n_local,
+// jittered with the first two uniforms of the path's stream.  False for a slot outside the image.  k_generate stores
+// the result; the PRIMARY variants of k_trace / k_shade recompute it instead, which removes the generate launch and the
+// 72 B per path it writes (and iteration 0 reads back) from every pass.
+HPT_DEV bool primary_ray(const PrimaryGen &g, uint32_t i, f3 &eye, f3 &dir, uint64_t &rs){
+    uint32_t p = i % (uint32_t) g.tl.n_local, j = i / (uint32_t) g.tl.n_local;
+    int px, py;
+    if(!tile_to_pixel(g.tl, p, px, py)) return false;
+    rs = rng_seed(g.seed, (uint32_t) (py * g.tl.W + px), g.first_sample + j);
+    float pixel_x = (float) px + rng_next(rs);
+    float pixel_y = (float) py + rng_next(rs);
+    eye = mk3(g.cam.eye[0], g.cam.eye[1], g.cam.eye[2]);
+    f3 pixel_pos = mk3(g.cam.UL[0], g.cam.UL[1], g.cam.UL[2]) + mk3(g.cam.dx[0], g.cam.dx[1], g.cam.dx[2]) * pixel_x
+                   + mk3(g.cam.dy[0], g.cam.dy[1], g.cam.dy[2]) * pixel_y;
+    dir = normalize3(pixel_pos - eye);
+    return true;
+}
+
 __global__ __launch_bounds__(kBlock)
 void k_generate(Tiling tl, CameraDev cam, PathBuf pb, uint32_t *qcount,
                 uint32_t total, uint32_t first_sample, uint64_t seed, WorkCounters *wc){
@@ -224,17 +242,10 @@ void k_generate(Tiling tl, CameraDev cam, PathBuf pb, uint32_t *qcount,
     if(blockIdx.x == 0 && threadIdx.x == 0) *qcount = total;
     uint32_t stride = gridDim.x * kBlock;
     for(uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += stride){
-        uint32_t p = i % (uint32_t) tl.n_local, j = i / (uint32_t) tl.n_local;
-        int px, py;
-        bool active = tile_to_pixel(tl, p, px, py);
+        PrimaryGen g; g.tl = tl; g.cam = cam; g.first_sample = first_sample; g.pad = 0u; g.seed = seed;
+        f3 eye = mk3(0, 0, 0), dir = mk3(0, 0, 1); uint64_t rs = 0ull;
+        bool active = primary_ray(g, i, eye, dir, rs);
         if(active){
-            uint64_t rs = rng_seed(seed, (uint32_t) (py * tl.W + px), first_sample + j);
-            float pixel_x = (float) px + rng_next(rs);
-            float pixel_y = (float) py + rng_next(rs);
-            f3 eye = mk3(cam.eye[0], cam.eye[1], cam.eye[2]);
-            f3 pixel_pos = mk3(cam.UL[0], cam.UL[1], cam.UL[2]) + mk3(cam.dx[0], cam.dx[1], cam.dx[2]) * pixel_x
-                           + mk3(cam.dy[0], cam.dy[1], cam.dy[2]) * pixel_y;
-            f3 dir = normalize3(pixel_pos - eye);
             pb.org_eta[i] = make_float4(eye.x, eye.y, eye.z, 1.0f);
             pb.dir_flags[i] = make_float4(dir.x, dir.y, dir.z, u2f(1u));      // last_is_delta = true, depth 0
             pb.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
@@ -303,10 +314,11 @@ constexpr int kLdsLights = 64;   // light records staged in LDS (7 KiB)
 constexpr int kShadeChunk = 2048;        // paths per workgroup at most (LDS staging capacity)
 constexpr int kShadeTargetGroups = 1024; // workgroups a short queue is spread over
 
+template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock)
 void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
              uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue, uint32_t *scount,
-             int max_depth, int max_delta, int roulette, WorkCounters *wc){
+             int max_depth, int max_delta, int roulette, WorkCounters *wc, PrimaryGen pg){
     __shared__ DevMaterial s_mats[kLdsMats];
     __shared__ DevLight s_lights[kLdsLights];
     // survivors and shadow requests of this workgroup's chunk are compacted in LDS (wave64
@@ -349,9 +361,18 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
             ++iters;
             uint2 h = pb.hit[path];
             uint32_t prim = h.y;
+            // PRIMARY (iteration 0 without a generate launch): the path state is not in memory yet -- the ray is recomputed
+            // from the slot number, throughput 1, depth 0, "last bounce was delta" so a light seen directly counts
+            // (pt_cu.cu:41-46); every slot's radiance record is initialised here (emission or zero)
+            f3 p_eye = mk3(0, 0, 0), p_dir = mk3(0, 0, 1), first_col = mk3(0, 0, 0); uint64_t p_rs = 0ull;
+            if(PRIMARY && !primary_ray(pg, path, p_eye, p_dir, p_rs)) prim = kHitMiss;
             if(prim != kHitMiss){                                     // miss ends the path (pt_cu.cu:54)
                 float t = u2f(h.x);
-                float4 o4 = pb.org_eta[path], d4 = pb.dir_flags[path], th4 = pb.thr[path];
+                float4 o4, d4, th4;
+                if(PRIMARY){
+                    o4 = make_float4(p_eye.x, p_eye.y, p_eye.z, 1.0f); d4 = make_float4(p_dir.x, p_dir.y, p_dir.z, u2f(1u));
+                    th4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                } else { o4 = pb.org_eta[path]; d4 = pb.dir_flags[path]; th4 = pb.thr[path]; }
                 f3 ro = xyz(o4), rd = xyz(d4), throughput = xyz(th4);
                 float ray_eta = o4.w;
                 uint32_t flags = f2u(d4.w);
@@ -409,9 +430,12 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                         f3 contrib = throughput * emission;
                         if(is_valid_color(contrib)){
                             f3 c = clamp_radiance(contrib, 15.0f);
-                            float4 col = pb.col[path];
-                            col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
-                            pb.col[path] = col;
+                            if(PRIMARY) first_col = mk3(0.0f + c.x, 0.0f + c.y, 0.0f + c.z);       // the sum starts at zero (pt_cu.cu:39)
+                            else {
+                                float4 col = pb.col[path];
+                                col.x = col.x + c.x; col.y = col.y + c.y; col.z = col.z + c.z;
+                                pb.col[path] = col;
+                            }
                         }
                     }
                     // BSDF-sampled light hits after a non-delta bounce add nothing (the reference's
@@ -425,8 +449,9 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     // its last bounce the sampled direction would never be used (pt_cu.cu:37, 228-241)
                     const bool delta_mat = (m.eta > 0.0f && m.roughness < 0.001f && m.metallic < 0.01f) || (m.metallic > 0.99f && m.roughness < 0.001f);
                     const bool last_bounce = !delta_mat && depth + 1 >= max_depth;
-                    uint2 r2 = pb.rng[path];
-                    uint64_t rs = ((uint64_t) r2.y << 32) | (uint64_t) r2.x;
+                    uint64_t rs;
+                    if(PRIMARY) rs = p_rs;
+                    else { uint2 r2 = pb.rng[path]; rs = ((uint64_t) r2.y << 32) | (uint64_t) r2.x; }
                     ShadeCtx ctx;
                     if(have_frame){ ctx.N = normal; ctx.T = frame_T; ctx.B = frame_B; ctx.wo = to_local(wo, frame_T, frame_B, normal); }
                     else ctx = make_shade_ctx(normal, wo);
@@ -532,6 +557,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     }
                 }
             }
+            if(PRIMARY) pb.col[path] = make_float4(first_col.x, first_col.y, first_col.z, 0.0f);
         }
         if(want_shadow){
             f3 diff = s_p2 - s_p1;                          // geometric.cuh:298-303
@@ -687,10 +713,10 @@ constexpr int kNodeMin = 4;           // fewer lanes than this still walking nod
                                       // (A/B: off 42.1 ms, 2: 39.9, 4: 39.4, 8: 40.2, 16: 41.3, 32: 43.2)
 constexpr uint32_t kTraceShortQueue = 1u << 20;   // below this many rays a workgroup takes 256 instead of kTraceChunk
 
-template <bool ANY, bool COUNT, bool RESUME, bool TOP>
+template <bool ANY, bool COUNT, bool RESUME, bool TOP, bool PRIMARY>
 HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *queue,
                          uint32_t end, uint32_t *stk, uint32_t *s_next, int refill_min, int node_min, WorkCounters *wc,
-                         uint32_t budget, uint32_t *s_long, uint32_t *s_nlong, const uint4 *top){
+                         uint32_t budget, uint32_t *s_long, uint32_t *s_nlong, const uint4 *top, const PrimaryGen &pg){
     bool active = false, exhausted = false;
     uint32_t path = 0u, cur = 0u, steps = 0u;
     int sp = 0;
@@ -749,9 +775,19 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                         }
                         limit = tmax;
                     } else {
-                        float4 o = pb.org_eta[path], d = pb.dir_flags[path];
-                        ro = xyz(o); rd = xyz(d);
-                        if(f2u(d.w) & 2u) start = false;                    // slot outside the image
+                        bool outside;
+                        if(PRIMARY){
+                            // iteration 0 without a generate launch: the camera ray of this slot, recomputed (the first
+                            // launch reads the identity queue, the resume launch the slots it was handed)
+                            uint64_t rs_unused;
+                            outside = !primary_ray(pg, path, ro, rd, rs_unused);
+                            if(outside && !RESUME) pb.hit[path] = make_uint2(f2u(1e20f), kHitMiss);
+                        } else {
+                            float4 o = pb.org_eta[path], d = pb.dir_flags[path];
+                            ro = xyz(o); rd = xyz(d);
+                            outside = (f2u(d.w) & 2u) != 0u;
+                        }
+                        if(outside) start = false;                          // slot outside the image
                         else if(RESUME){
                             // restart with the closest hit of the first launch as the limit
                             uint2 h = pb.hit[path];
@@ -906,11 +942,11 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
 // is the same (closest hit with the ordinal tie-break, or the occlusion boolean, of the same ray).
 struct LongQueues { uint32_t *equeue, *ecount, *squeue, *scount; uint32_t budget; };
 
-template <bool COUNT, bool RESUME, bool TOP>
+template <bool COUNT, bool RESUME, bool TOP, bool PRIMARY>
 __global__ __launch_bounds__(kBlock)
 void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, const uint32_t *ecount_ptr,
              const uint32_t *squeue, const uint32_t *scount_ptr, uint32_t chunk_rays, int refill_min, int node_min,
-             int stack_words, LongQueues lq, WorkCounters *wc){
+             int stack_words, LongQueues lq, WorkCounters *wc, PrimaryGen pg){
     extern __shared__ uint32_t s_dyn_stack[];        // [stack level][lane], sized by the BVH depth; then the long-ray list
     __shared__ uint32_t s_next, s_nlong, s_gbase;
     __shared__ uint4 s_top[TOP ? kTopNodes * 2 : 1];  // the top of the quantised tree (first launch of a split step)
@@ -934,10 +970,10 @@ void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, cons
         uint32_t end = begin + csize < total ? begin + csize : total;
         if(threadIdx.x == 0){ s_next = begin; s_nlong = 0u; }
         __syncthreads();
-        if(shadow) trace_chunk<true, COUNT, RESUME, TOP>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
-                                                         lq.budget, s_long, &s_nlong, s_top);
-        else trace_chunk<false, COUNT, RESUME, TOP>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
-                                                    lq.budget, s_long, &s_nlong, s_top);
+        if(shadow) trace_chunk<true, COUNT, RESUME, TOP, false>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
+                                                                lq.budget, s_long, &s_nlong, s_top, pg);
+        else trace_chunk<false, COUNT, RESUME, TOP, PRIMARY>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
+                                                             lq.budget, s_long, &s_nlong, s_top, pg);
         __syncthreads();
         if(!RESUME && lq.budget != 0u){
             uint32_t n = s_nlong;
@@ -1060,14 +1096,17 @@ void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t
 
 void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
                   uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue,
-                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc){
+                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc, const PrimaryGen *primary){
     // enough workgroups for either chunking regime (see k_shade)
     uint32_t g = (max_items + kShadeChunk - 1) / kShadeChunk;
     if(g < (uint32_t) kShadeTargetGroups) g = (uint32_t) kShadeTargetGroups;
     uint32_t small = (max_items + kBlock - 1) / kBlock;
     if(small < g) g = small < 1u ? 1u : small;
-    hipLaunchKernelGGL(k_shade, dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
-                       next_count, sb, squeue, scount, max_depth, max_delta, roulette, wc);
+    PrimaryGen none{};
+    if(primary) hipLaunchKernelGGL((k_shade<true>), dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
+                                   next_count, sb, squeue, scount, max_depth, max_delta, roulette, wc, *primary);
+    else hipLaunchKernelGGL((k_shade<false>), dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
+                            next_count, sb, squeue, scount, max_depth, max_delta, roulette, wc, none);
 }
 
 void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,
@@ -1082,7 +1121,8 @@ void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb,
 
 void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue,
                   const uint32_t *ecount, uint32_t max_extend, const uint32_t *squeue, const uint32_t *scount,
-                  uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc, const TraceSplit *split){
+                  uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc, const TraceSplit *split,
+                  const PrimaryGen *primary){
     uint32_t chunk = ((tuning >> 16) & 0xFF) ? (uint32_t) ((tuning >> 16) & 0xFF) * 256u : (uint32_t) kTraceChunk;
     int refill_min = ((tuning >> 8) & 0xFF) ? ((tuning >> 8) & 0xFF) : kRefillMin;
     int node_min = ((tuning >> 24) & 0x7F) ? ((tuning >> 24) & 0x7F) : kNodeMin;
@@ -1110,15 +1150,22 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
     }
     size_t lds = (size_t) stack_words * sizeof(uint32_t) + (lq.budget ? (size_t) chunk * sizeof(uint32_t) : 0);
     const bool top = lq.budget != 0u && lq.budget <= (uint32_t) kTopLevels && !(tuning & 0x80);       // tuning bit 7: node fetches from global memory (A/B)
-    if(count) hipLaunchKernelGGL((k_trace<true, false, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
-    else if(top) hipLaunchKernelGGL((k_trace<false, false, true>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
-    else hipLaunchKernelGGL((k_trace<false, false, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, scount, chunk, refill_min, node_min, stack_words, lq, wc);
+    PrimaryGen none{};
+    const PrimaryGen &pg = primary ? *primary : none;
+#define HPT_LAUNCH_TRACE(C, T, P) hipLaunchKernelGGL((k_trace<C, false, T, P>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, \
+                                                     scount, chunk, refill_min, node_min, stack_words, lq, wc, pg)
+    if(count) HPT_LAUNCH_TRACE(true, false, false);
+    else if(top && primary) HPT_LAUNCH_TRACE(false, true, true);
+    else if(top) HPT_LAUNCH_TRACE(false, true, false);
+    else if(primary) HPT_LAUNCH_TRACE(false, false, true);
+    else HPT_LAUNCH_TRACE(false, false, false);
+#undef HPT_LAUNCH_TRACE
 }
 
 // second launch of a split trace step: the rays launch_trace set aside.  Their number is only known on
 // the device, so a fixed grid walks the chunks.
 void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
-                         uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split){
+                         uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split, const PrimaryGen *primary){
     if(!extend && !shadow) return;
     if(stack_levels < 1) stack_levels = 1;
     if(stack_levels > kStackDepth) stack_levels = kStackDepth;
@@ -1130,9 +1177,15 @@ void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBu
     uint64_t g = (uint64_t) per * ((extend ? 1u : 0u) + (shadow ? 1u : 0u));
     uint32_t g2 = g < 8192u ? (uint32_t) (g < 1u ? 1u : g) : 8192u;
     LongQueues none{};
-    hipLaunchKernelGGL((k_trace<false, true, false>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
-                       extend ? split.equeue : nullptr, extend ? split.ecount : nullptr, shadow ? split.squeue : nullptr,
-                       shadow ? split.scount : nullptr, chunk2, refill2, node_min2, stack_words, none, wc);
+    PrimaryGen no_primary{};
+    if(primary && extend)
+        hipLaunchKernelGGL((k_trace<false, true, false, true>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
+                           split.equeue, split.ecount, shadow ? split.squeue : nullptr, shadow ? split.scount : nullptr, chunk2, refill2,
+                           node_min2, stack_words, none, wc, *primary);
+    else
+        hipLaunchKernelGGL((k_trace<false, true, false, false>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
+                           extend ? split.equeue : nullptr, extend ? split.ecount : nullptr, shadow ? split.squeue : nullptr,
+                           shadow ? split.scount : nullptr, chunk2, refill2, node_min2, stack_words, none, wc, no_primary);
 }
 
 void launch_tri_frames(hipStream_t s, const float4 *tris, int num_tris, float4 *frames){
