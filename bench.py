@@ -281,7 +281,7 @@ def main():
             trace_s_per_render = (ext_ms + res_ms) / max(args.steps, 1) * 1e-3
             # PMC figures are never measured by this run: quoted only from a file taken from this very build and workload
             pmc = None
-            default_workload = (args.size, args.tris, args.depth) == (1024, 100_000, 4) and args.spp >= 64
+            default_workload = (args.size, args.tris, args.depth) == (1024, 100_000, 4) and args.spp >= 128
             if os.path.exists(args.pmc_file) and default_workload:
                 try:
                     cand = json.load(open(args.pmc_file))

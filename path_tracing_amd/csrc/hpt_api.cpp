@@ -254,17 +254,16 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     const bool legacy = brute || (P.reserved & 1);          // separate extend/connect kernels (the scan variants)
     const int kflags = (brute ? 1 : 0) | (count ? 2 : 0) | ((flags >> 16) & 1 ? 4 : 0);      // flags bits 16-31: development switches
 
-    // Samples in flight per pass: about 64 Mi path slots (9.5 GiB of path state, queues and shadow records:
-    // nothing on a 288 GB device).  Fewer, larger passes amortise the low-occupancy tail iterations of every
-    // pass (config 3, ms per 256-spp render: 4 Mi slots 291, 8 Mi 243, 16 Mi 219, 64 Mi 196, 256 Mi 192).
-    // Two passes are in flight at a time, on two streams with a workspace each: while one pipeline's kernel
-    // drains or waits on memory the other's waves take the issue slots (config 3: 167 -> 160 ms).  A render
-    // that fits one pass stays one pass: two concurrent half-size passes are no faster than it (64 Mi slots:
-    // 43.9 vs 42.1 ms; 32 Mi: 22.8 vs 22.6).
+    // Samples in flight per pass: about 128 Mi path slots (19 GiB of path state, queues and shadow records per pipeline:
+    // little on a 288 GB device).  Fewer, larger passes amortise the low-occupancy tail iterations of every pass
+    // (config 3, ms per 256-spp render, one pipeline: 4 Mi slots 291, 16 Mi 219, 64 Mi 146, 128 Mi 142, 256 Mi 139).
+    // Two passes are in flight at a time, on two streams with a workspace each: while one pipeline's kernel drains or
+    // waits on memory the other's waves take the issue slots (64 Mi slots each: 138.1 ms, 128 Mi each: 135.7).  A render
+    // that fits one pass stays one pass: two concurrent half-size passes are no faster than it.
     bool dual = !(flags & HPT_FLAG_SINGLE_PIPELINE) && !count && !legacy;
     int spass = P.samples_per_pass;
     if(spass <= 0){
-        const long long target = 64ll << 20;
+        const long long target = 128ll << 20;
         spass = (int) std::max<long long>(1, target / tl.n_local);
         spass = std::min(spass, spp);
     }

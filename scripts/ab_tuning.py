@@ -17,7 +17,7 @@ ref = None
 with hpt.Scene(L, sp, tr) as scene:
     for r in range(int(os.environ.get("AB_ROUNDS", "5")) + 1):
         for v in variants:
-            p = hpt.make_params(seed=1, flags=flags | v[1]); p.reserved = v[0]
+            p = hpt.make_params(seed=1, flags=flags | v[1], samples_per_pass=int(os.environ.get("AB_SPASS", "0"))); p.reserved = v[0]
             img = scene.render_pt(cam, W, H, 4, spp, p)
             st = scene.stats()
             if ref is None: ref = img

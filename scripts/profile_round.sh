@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile of the bench workload.  Usage on the GPU box:  bash scripts/profile_round.sh <tag>
 #   trace / trace_single   rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1` (two pipelines / one)
-#   pass_*                 one 64-spp pass (`--steps 1 --warmup 0 --spp 64 --single-pipeline`, nothing else rendered:
+#   pass_*                 one 128-spp pass (`--steps 1 --warmup 0 --spp 128 --single-pipeline`, nothing else rendered:
 #                          no counting render, no exclusive step), one PMC counter set per run -- counters are never
 #                          combined with anything but --kernel-trace
 # Results land in gpurun_out/<tag>/; scripts/profile_summarize.py <tag> turns them into profiles/<tag>_*.
@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 
 echo "trace exit $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --single-pipeline --no-count-step > "$OUT/trace_single.log" 2> "$OUT/trace_single.err"
 echo "trace (single pipeline) exit $?"
-ONE="--steps 1 --warmup 0 --spp 64 --no-cpu-baseline --single-pipeline --no-count-step"
+ONE="--steps 1 --warmup 0 --spp 128 --no-cpu-baseline --single-pipeline --no-count-step"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pass_timeline" -- python3 "$ROOT/bench.py" $ONE > "$OUT/pass_timeline.log" 2> "$OUT/pass_timeline.err"
 echo "pass timeline exit $?"
 pmc () {

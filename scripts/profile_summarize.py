@@ -29,7 +29,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ", "SQ2", "TA1", "TA2"):
         out[k]["dispatches"] = len(disp[k])
 import bench
 res = {"tag": tag, "kernel_source_sha": bench.kernel_source_sha(),
-       "workload": "bench.py --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --single-pipeline --no-count-step (cfg3 scene, 1024x1024; exactly ONE 64 Mi-slot pass "
+       "workload": "bench.py --steps 1 --warmup 0 --spp 128 --no-cpu-baseline --single-pipeline --no-count-step (cfg3 scene, 1024x1024; exactly ONE 128 Mi-slot pass "
                    "is rendered = the launch sizes of the 256-spp bench), one PMC counter set per run",
        "note": "FETCH_SIZE/WRITE_SIZE are in KiB, summed over the kernel's dispatches; on gfx950 FETCH_SIZE tallies 128-B "
                "requests as 64 B (MI355X_MICROARCH.md, HBM section): read bytes = 2 x FETCH_SIZE x 1024; counts fabric-side "
@@ -63,7 +63,7 @@ if kf and kf.get("valu_utilization") is not None:
 try:
     line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
     b = json.loads(line)
-    iters = b["work"]["path_iterations_per_sample"] * 1024 * 1024 * 64
+    iters = b["work"]["path_iterations_per_sample"] * 1024 * 1024 * 128
     res["path_iterations_per_pass"] = iters
     ksh = res["kernels"].get("k_shade")
     if ksh and "read_bytes_corrected" in ksh and "write_bytes" in ksh:
