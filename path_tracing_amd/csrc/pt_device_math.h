@@ -178,10 +178,9 @@ HPT_DEV ShadeCtx make_shade_ctx(f3 N, f3 wo_w){
 // several queries at one hit: the diffuse lobe (a per-material constant) and Lambda(wo).
 struct ShadePre { f3 diffuse; float lam_o; };
 
+// (wo, wi in the local frame of the hit; bsdf_eval_pdf below projects a world direction first)
 template <bool WANT_F = true, bool WANT_PDF = true>
-HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, float &pdf_out, const ShadePre *pre = nullptr){
-    f3 wo = c.wo;
-    f3 wi = to_local(wi_w, c.T, c.B, c.N);
+HPT_DEV void bsdf_eval_pdf_local(const Mat &m, f3 wo, f3 wi, f3 &f_out, float &pdf_out, const ShadePre *pre = nullptr){
     f_out = mk3(0, 0, 0); pdf_out = 0.0f;
     bool eval_zero = !WANT_F || (wo.z == 0.0f || wi.z == 0.0f);
     bool pdf_zero = !WANT_PDF || (wo.z * wi.z <= 0.0f);
@@ -214,6 +213,11 @@ HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, 
         float diff_weight = 1.0f - spec_weight;
         pdf_out = diff_weight * pdf_diffuse + spec_weight * pdf_specular;
     }
+}
+
+template <bool WANT_F = true, bool WANT_PDF = true>
+HPT_DEV void bsdf_eval_pdf(const Mat &m, const ShadeCtx &c, f3 wi_w, f3 &f_out, float &pdf_out, const ShadePre *pre = nullptr){
+    bsdf_eval_pdf_local<WANT_F, WANT_PDF>(m, c.wo, to_local(wi_w, c.T, c.B, c.N), f_out, pdf_out, pre);
 }
 
 // BSDF sampling (geometric.cuh:486-562).  pdf <= 0 means "terminate the path" for both the

@@ -309,10 +309,14 @@ void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue, co
     if(COUNT) flush_tally(tally, rays, wc, true);
 }
 
-constexpr int kLdsMats = 256;    // material records staged in LDS (12 KiB)
-constexpr int kLdsLights = 64;   // light records staged in LDS (7 KiB)
-constexpr int kShadeChunk = 2048;        // paths per workgroup at most (LDS staging capacity)
+constexpr int kLdsMats = 128;    // material records staged in LDS (6 KiB)
+constexpr int kLdsLights = 32;   // light records staged in LDS (3.5 KiB)
+constexpr int kShadeChunk = 1024;        // paths per workgroup at most (LDS staging capacity)
 constexpr int kShadeTargetGroups = 1024; // workgroups a short queue is spread over
+// Next-event candidates of a wave are staged in LDS and evaluated 64 at a time (see k_shade): words per record
+constexpr int kNeeWords = 20;
+// 0-2 wo (local) | 3-5 wi (local) | 6 Lambda(wo) | 7 material index | 8-10 throughput | 11 pdf_light_dir |
+// 12-14 shadow segment start | 15-17 shadow segment end | 18 path slot | 19 light index | parallel << 31
 
 template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock)
@@ -327,6 +331,59 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     __shared__ uint32_t s_next[kShadeChunk];
     __shared__ uint32_t s_shadow[kShadeChunk];
     __shared__ uint32_t s_cnt[4];          // [0] survivors, [1] shadow requests, [2],[3] global bases
+    // Next-event estimation is evaluated DENSELY.  Only about a third of the lanes of a trip get past the cosine and
+    // cone tests, and the BSDF value + pdf + MIS + shadow-record code behind them is ~30 % of this kernel's time
+    // (knock-out: 16.3 -> 11.2 ms per pass).  So a lane that passes leaves a 20-word record in its wave's LDS staging
+    // area instead of evaluating; once 64 records are waiting (about three trips) the wave evaluates them with every
+    // lane busy.  Same expressions on the same operands, so the contributions are bit-identical; only the order of the
+    // shadow queue changes, which nothing depends on.  Wave-private: no barrier, the count lives in a register.
+    __shared__ uint32_t s_stage[kBlock / 64][kNeeWords][64];
+    uint32_t (*stage)[64] = s_stage[threadIdx.x >> 6];
+    uint32_t staged = 0u;                  // records waiting in this wave's staging area (wave-uniform)
+    const uint32_t lane = threadIdx.x & 63u;
+    // evaluates the first n staged records, one per lane (pt_cu.cu:136-146 parallel lights, :179-196 ball lights)
+    auto flush_nee = [&](uint32_t n){
+        bool want = false; uint32_t spath = 0u;
+        if(lane < n){
+            f3 wo_l = mk3(u2f(stage[0][lane]), u2f(stage[1][lane]), u2f(stage[2][lane]));
+            f3 wi_l = mk3(u2f(stage[3][lane]), u2f(stage[4][lane]), u2f(stage[5][lane]));
+            ShadePre pre; pre.lam_o = u2f(stage[6][lane]);
+            const uint32_t mat_i = stage[7][lane], light_i = stage[19][lane];
+            f3 thr = mk3(u2f(stage[8][lane]), u2f(stage[9][lane]), u2f(stage[10][lane]));
+            const float pdf_light_dir = u2f(stage[11][lane]);
+            f3 p1 = mk3(u2f(stage[12][lane]), u2f(stage[13][lane]), u2f(stage[14][lane]));
+            f3 p2 = mk3(u2f(stage[15][lane]), u2f(stage[16][lane]), u2f(stage[17][lane]));
+            spath = stage[18][lane];
+            const DevMaterial dm = (sc.num_mats <= kLdsMats ? s_mats : sc.mats)[mat_i];
+            const DevLight &L = (sc.num_lights <= kLdsLights ? s_lights : sc.lights)[light_i & 0x7FFFFFFFu];
+            Mat m; m.base = mk3(dm.base[0], dm.base[1], dm.base[2]); m.roughness = dm.roughness; m.metallic = dm.metallic; m.eta = dm.eta;
+            pre.diffuse = mk3(dm.diffuse[0], dm.diffuse[1], dm.diffuse[2]);
+            f3 illum = mk3(L.illum[0], L.illum[1], L.illum[2]);
+            f3 brdf; float pdf_bsdf;
+            bsdf_eval_pdf_local(m, wo_l, wi_l, brdf, pdf_bsdf, &pre);
+            const float cos_surface = fmaxf(0.0f, wi_l.z);           // = max(0, dot(normal, wi)): the frame's third axis is the normal
+            f3 contrib;
+            if(light_i >> 31) contrib = thr * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface * (float) sc.num_lights;
+            else {
+                float p_l = pdf_light_dir * pdf_light_dir;
+                float p_b = pdf_bsdf * pdf_bsdf;
+                float mis_w = p_l / fmaxf(p_l + p_b, 1e-8f);
+                contrib = thr * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface / pdf_light_dir * mis_w;
+            }
+            if(is_valid_color(contrib)){
+                want = true;
+                f3 c = clamp_radiance(contrib, 15.0f);
+                f3 diff = p2 - p1;                              // geometric.cuh:298-303
+                float dist = length3(diff);
+                f3 dir = diff / dist;
+                sb.org_max[spath] = make_float4(p1.x, p1.y, p1.z, dist - 1e-3f);
+                sb.dir[spath] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+                sb.contrib[spath] = make_float4(c.x, c.y, c.z, 0.0f);
+            }
+        }
+        uint32_t spos = lds_push(want, &s_cnt[1]);
+        if(want) s_shadow[spos] = spath;
+    };
     if(threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
     const bool mats_in_lds = sc.num_mats <= kLdsMats;
     const bool lights_in_lds = sc.num_lights <= kLdsLights;
@@ -353,9 +410,11 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     uint32_t iters = 0;
     for(uint32_t base = begin; base < end; base += kBlock){
         uint32_t i = base + threadIdx.x;
-        bool alive = false, want_shadow = false;
+        bool alive = false, nee = false;
         uint32_t path = 0;
-        f3 s_p1 = mk3(0, 0, 0), s_p2 = mk3(0, 0, 0), s_contrib = mk3(0, 0, 0);
+        // the next-event candidate of this lane's path, if it gets one (record layout: kNeeWords)
+        f3 n_wo = mk3(0, 0, 0), n_wi = mk3(0, 0, 0), n_thr = mk3(0, 0, 0), s_p1 = mk3(0, 0, 0), s_p2 = mk3(0, 0, 0);
+        float n_lam = 0.0f, n_pdf_light = 0.0f; uint32_t n_mat = 0u, n_light = 0u;
         if(i < count){
             path = queue ? queue[i] : i;
             ++iters;
@@ -456,25 +515,25 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     if(have_frame){ ctx.N = normal; ctx.T = frame_T; ctx.B = frame_B; ctx.wo = to_local(wo, frame_T, frame_B, normal); }
                     else ctx = make_shade_ctx(normal, wo);
                     pre.lam_o = ggx_lambda(ctx.wo, roughness_to_alpha(m.roughness));     // shared by the NEE and the sampled query
+                    // the hit-level words of a next-event record are set HERE, outside the nested branches behind the rejection
+                    // loop: hipcc 7.2 at -O3 zeroes single components of values assigned in there (round 1 met the same
+                    // miscompile; with these five assignments inside `if(inside_cone)` the green channel of every contribution
+                    // came out 0 -- tests/test_gpu_parity.py on input.txt catches it)
+                    n_wo = ctx.wo; n_lam = pre.lam_o; n_thr = throughput; n_mat = mat_idx;
+                    s_p1 = pos + normal * kEps;
 
                     // next-event estimation, pt_cu.cu:125-202
                     if(m.eta <= 0.0f && (m.metallic < 0.99f || m.roughness > 0.01f) && sc.num_lights > 0){
                         int l_idx = min((int) (rng_next(rs) * sc.num_lights), sc.num_lights - 1);
                         const DevLight &L = lights[l_idx];
-                        f3 illum = mk3(L.illum[0], L.illum[1], L.illum[2]);
                         if(L.is_parallel){
                             f3 light_dir = mk3(L.neg_dir[0], L.neg_dir[1], L.neg_dir[2]);
                             float cos_surface = fmaxf(0.0f, dot3(normal, light_dir));
                             if(cos_surface > 0.0f){
-                                f3 brdf; float pdf_unused;
-                                bsdf_eval_pdf(m, ctx, light_dir, brdf, pdf_unused, &pre);
-                                f3 contrib = throughput * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface * (float) sc.num_lights;
-                                if(is_valid_color(contrib)){
-                                    want_shadow = true;
-                                    s_p1 = pos + normal * kEps;
-                                    s_p2 = pos + light_dir * 1e4f;
-                                    s_contrib = clamp_radiance(contrib, 15.0f);
-                                }
+                                nee = true;
+                                n_wi = to_local(light_dir, ctx.T, ctx.B, ctx.N);
+                                n_light = (uint32_t) l_idx | 0x80000000u;
+                                s_p2 = pos + light_dir * 1e4f;
                             }
                         } else {
                             f3 d_local;
@@ -498,19 +557,11 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                                 }
                                 if(inside_cone){
                                     float pdf_light_area = 1.0f / (sc.num_lights * L.area);
-                                    float pdf_light_dir = pdf_light_area * dist2 / fmaxf(cos_light, 1e-6f);
-                                    f3 brdf; float pdf_bsdf;
-                                    bsdf_eval_pdf(m, ctx, wi_light, brdf, pdf_bsdf, &pre);
-                                    float p_l = pdf_light_dir * pdf_light_dir;
-                                    float p_b = pdf_bsdf * pdf_bsdf;
-                                    float mis_w = p_l / fmaxf(p_l + p_b, 1e-8f);
-                                    f3 contrib = throughput * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface / pdf_light_dir * mis_w;
-                                    if(is_valid_color(contrib)){
-                                        want_shadow = true;
-                                        s_p1 = pos + normal * kEps;
-                                        s_p2 = light_pos + d_local * kEps;
-                                        s_contrib = clamp_radiance(contrib, 15.0f);
-                                    }
+                                    nee = true;
+                                    n_pdf_light = pdf_light_area * dist2 / fmaxf(cos_light, 1e-6f);
+                                    n_wi = to_local(wi_light, ctx.T, ctx.B, ctx.N);
+                                    n_light = (uint32_t) l_idx;
+                                    s_p2 = light_pos + d_local * kEps;
                                 }
                             }
                         }
@@ -559,19 +610,30 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
             }
             if(PRIMARY) pb.col[path] = make_float4(first_col.x, first_col.y, first_col.z, 0.0f);
         }
-        if(want_shadow){
-            f3 diff = s_p2 - s_p1;                          // geometric.cuh:298-303
-            float dist = length3(diff);
-            f3 dir = diff / dist;
-            sb.org_max[path] = make_float4(s_p1.x, s_p1.y, s_p1.z, dist - 1e-3f);
-            sb.dir[path] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-            sb.contrib[path] = make_float4(s_contrib.x, s_contrib.y, s_contrib.z, 0.0f);
+        // stage this trip's next-event candidates; evaluate when the wave's staging area would overflow
+        {
+            const unsigned long long cm = __ballot(nee);
+            if(cm != 0ull){
+                const uint32_t k = (uint32_t) __popcll(cm);
+                if(staged + k > 64u){ flush_nee(staged); staged = 0u; }
+                if(nee){
+                    const uint32_t slot = staged + __builtin_amdgcn_mbcnt_hi((uint32_t) (cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) cm, 0u));
+                    stage[0][slot] = f2u(n_wo.x); stage[1][slot] = f2u(n_wo.y); stage[2][slot] = f2u(n_wo.z);
+                    stage[3][slot] = f2u(n_wi.x); stage[4][slot] = f2u(n_wi.y); stage[5][slot] = f2u(n_wi.z);
+                    stage[6][slot] = f2u(n_lam); stage[7][slot] = n_mat;
+                    stage[8][slot] = f2u(n_thr.x); stage[9][slot] = f2u(n_thr.y); stage[10][slot] = f2u(n_thr.z);
+                    stage[11][slot] = f2u(n_pdf_light);
+                    stage[12][slot] = f2u(s_p1.x); stage[13][slot] = f2u(s_p1.y); stage[14][slot] = f2u(s_p1.z);
+                    stage[15][slot] = f2u(s_p2.x); stage[16][slot] = f2u(s_p2.y); stage[17][slot] = f2u(s_p2.z);
+                    stage[18][slot] = path; stage[19][slot] = n_light;
+                }
+                staged += k;
+            }
         }
-        uint32_t spos = lds_push(want_shadow, &s_cnt[1]);
-        if(want_shadow) s_shadow[spos] = path;
         uint32_t qpos = lds_push(alive, &s_cnt[0]);
         if(alive) s_next[qpos] = path;
     }
+    if(staged != 0u) flush_nee(staged);
     __syncthreads();
     if(threadIdx.x == 0){
         s_cnt[2] = s_cnt[0] ? atomicAdd(next_count, s_cnt[0]) : 0u;
