@@ -515,10 +515,10 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                     if(have_frame){ ctx.N = normal; ctx.T = frame_T; ctx.B = frame_B; ctx.wo = to_local(wo, frame_T, frame_B, normal); }
                     else ctx = make_shade_ctx(normal, wo);
                     pre.lam_o = ggx_lambda(ctx.wo, roughness_to_alpha(m.roughness));     // shared by the NEE and the sampled query
-                    // the hit-level words of a next-event record are set HERE, outside the nested branches behind the rejection
-                    // loop: hipcc 7.2 at -O3 zeroes single components of values assigned in there (round 1 met the same
-                    // miscompile; with these five assignments inside `if(inside_cone)` the green channel of every contribution
-                    // came out 0 -- tests/test_gpu_parity.py on input.txt catches it)
+                    // the hit-level words of a next-event record are set here, outside the nested branches behind the rejection
+                    // loop.  (With them inside both branches hipcc 7.2's SLP vectorizer dropped the y component of the packed
+                    // x/y pairs -- green = 0 in every contribution, caught by tests/test_gpu_parity.py on input.txt; the build
+                    // now passes -fno-slp-vectorize, see the Makefile.)
                     n_wo = ctx.wo; n_lam = pre.lam_o; n_thr = throughput; n_mat = mat_idx;
                     s_p1 = pos + normal * kEps;
 
