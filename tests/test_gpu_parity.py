@@ -559,3 +559,41 @@ def test_random_scenes_bdpt_match_the_oracle(hpt, sio, oracle_mod, seed):
         nog = scene.render_bdpt(cam, W, H, 4, 4, spp, spl, hpt.make_params(seed=seed))
     assert_parity(img, ref)
     assert np.array_equal(img, ref) and np.array_equal(nog, ref)
+
+
+def test_many_materials_and_lights_beyond_the_lds_staging(hpt, sio, oracle_mod):
+    """More materials (> 128) and lights (> 32) than k_shade stages in LDS, an image large enough for several trips per
+    workgroup (the next-event records of three trips are evaluated together) and a mix of ball, cone and parallel
+    lights: the global-memory paths of the shading kernel and of its staged evaluation equal the oracle bit for bit."""
+    rng = np.random.default_rng(77)
+    n = 400
+    rows = [t for _, tl in sio._CORNELL_WALLS for t in tl]
+    mats = [m6 for m6, tl in sio._CORNELL_WALLS for _ in tl]
+    c = rng.uniform([-0.4, -0.4, -0.1], [0.4, 0.4, 0.9], size=(n, 1, 3))
+    v = (c + rng.uniform(-0.1, 0.1, size=(n, 3, 3))).reshape(n, 9)
+    rows += [tuple(r) for r in v.astype(np.float32)]
+    for k in range(n):                                             # every triangle its own material
+        kind = k % 4
+        base = tuple(rng.uniform(0.1, 1.0, size=3))
+        mats.append(base + ((1.0, 0.0, 0.0) if kind == 0 else (float(rng.uniform(0.2, 0.8)), 0.0, 0.0) if kind == 1
+                            else (float(rng.uniform(0.1, 0.5)), 0.9, 0.0) if kind == 2 else (0.0, 1.0, 0.0)))
+    tris = sio._tris_from(rows, mats)
+    lights = []
+    for k in range(40):
+        pos = tuple(rng.uniform([-0.4, 0.1, -0.1], [0.4, 0.45, 0.9]))
+        if k % 5 == 4:
+            lights.append(sio._one_light(pos, (0.1, -1.0, 0.2), (0.05, 0.05, 0.05), 0.0, 1, 0.03))
+        else:
+            lights.append(sio._one_light(pos, (0.0, -1.0, 0.0), tuple(rng.uniform(0.02, 0.1, size=3)), 180.0 if k % 2 else 50.0, 0, 0.03))
+    L = np.concatenate(lights)
+    sp = np.zeros(0, sio.SPHERE)
+    W, H, depth, spp = 160, 120, 4, 4            # 76 800 paths per sample: 1024-path chunks, four trips per workgroup
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, W, H)
+    ref, st = oracle_mod.pt_render(L, sp, tr := tris, cam, W, H, depth, spp, seed=5)
+    with hpt.Scene(L, sp, tr) as scene:
+        assert scene.stats()["n_materials"] > 128
+        img = scene.render_pt(cam, W, H, depth, spp, hpt.make_params(seed=5, flags=hpt.FLAG_COUNT_WORK))
+        gs = scene.stats()
+        fast = scene.render_pt(cam, W, H, depth, spp, hpt.make_params(seed=5))
+    assert st["shadow_rays"] > 50_000 and gs["shadow_rays"] == st["shadow_rays"]
+    assert np.array_equal(img, ref) and np.array_equal(fast, ref)
