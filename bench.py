@@ -333,7 +333,9 @@ def main():
             shade_bytes = 156.0 * wc["path_iters"]       # 28 B material + 2 x 64 B path state per (path, bounce)
             shade_s = shd_ms / max(args.steps, 1) * 1e-3
             out["roofline_shade"] = {
-                "bound": "hbm", "binding_limit": "valu issue", "kernel": "k_shade",
+                "bound": "hbm", "binding_limit": "valu issue and the latency of its gathers together (DESIGN.md section 5: a fifth fewer VALU "
+                                                 "instructions changed its time by 1 % alone on the device, 3.3 % of the render with two pipelines)",
+                "kernel": "k_shade",
                 "achieved": shade_bytes / shade_s / 1e9 if shade_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": shade_bytes / shade_s / 1e9 / HBM_PEAK_GBS if shade_s > 0 else None,
                 "avg_launch_ms": shd_ms / max(shd_n, 1), "launches_per_step": shd_n / max(args.steps, 1),

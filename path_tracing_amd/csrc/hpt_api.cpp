@@ -229,12 +229,22 @@ struct LaunchTimer {        // brackets one launch with events when TIME_KERNELS
     ~LaunchTimer(){ if(on){ hipEventRecord(tl.b, st); s->timed.push_back(tl); } }
 };
 
+// The scene's buffers live on the device that was current when it was created; launching from a thread whose current
+// device is another one would hand those pointers to the wrong GPU (a fault, not an error code).
+int on_scene_device(const hpt_scene *s){
+    int dev = -1;
+    if(hipGetDevice(&dev) != hipSuccess || dev != s->device)
+        return fail(HPT_ERR_INVALID, "the scene lives on another device than the calling thread's current one (hipSetDevice first)");
+    return HPT_OK;
+}
+
 // the wavefront render loop; everything is enqueued on `stream`
 int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, int spp,
                  const hpt_params *params, float *d_local, hipStream_t stream){
     if(!s) return fail(HPT_ERR_INVALID, "null scene");
     if(!camera || !d_local) return fail(HPT_ERR_INVALID, "null camera or output");
     if(spp <= 0 || eye_depth <= 0 || eye_depth > 255) return fail(HPT_ERR_INVALID, "spp must be > 0 and eye_depth in [1, 255]");
+    if(int rcd = on_scene_device(s)) return rcd;
     hpt_params P; memset(&P, 0, sizeof P);
     if(params) P = *params;
     if(P.max_delta <= 0) P.max_delta = 64;
@@ -259,13 +269,17 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     // (config 3, ms per 256-spp render, one pipeline: 4 Mi slots 291, 16 Mi 219, 64 Mi 146, 128 Mi 142, 256 Mi 139).
     // Two passes are in flight at a time, on two streams with a workspace each: while one pipeline's kernel drains or
     // waits on memory the other's waves take the issue slots (64 Mi slots each: 138.1 ms, 128 Mi each: 135.7).  A render
-    // that fits one pass stays one pass: two concurrent half-size passes are no faster than it.
+    // that fits one pass is cut into two half passes for the same reason -- the share of one rank of a multi-GPU render
+    // is such a render (rank 0 of 4 at config 3, 64 Mi slots: one pass 37.2-37.4 ms, two half passes 35.3-36.5; of 2:
+    // 72.1 -> 68.2; of 8: 19.5 -> 18.7; on another box 35.4 against 35.6: never a loss beyond the noise) -- unless it is
+    // so small (< 1 Mi slots) that launch latencies are what it costs.
     bool dual = !(flags & HPT_FLAG_SINGLE_PIPELINE) && !count && !legacy;
     int spass = P.samples_per_pass;
     if(spass <= 0){
         const long long target = 128ll << 20;
         spass = (int) std::max<long long>(1, target / tl.n_local);
         spass = std::min(spass, spp);
+        if(dual && spass == spp && spp >= 2 && (long long) tl.n_local * spp >= (1ll << 20)) spass = (spp + 1) / 2;
     }
     spass = std::min(spass, spp);
     const int npass = (spp + spass - 1) / spass;
@@ -569,6 +583,7 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
     if(!camera || !d_local) return fail(HPT_ERR_INVALID, "null camera or output");
     if(spp <= 0 || spl <= 0 || eye_depth <= 0 || eye_depth > 255 || light_depth <= 0 || light_depth > 255)
         return fail(HPT_ERR_INVALID, "spp, spl must be > 0 and depths in [1, 255]");
+    if(int rcd = on_scene_device(s)) return rcd;
     hpt_params P; memset(&P, 0, sizeof P);
     if(params) P = *params;
     if(P.max_delta <= 0) P.max_delta = 64;            // the CPU renderer has no cap (cpu_bdpt.cpp:458)

@@ -457,7 +457,16 @@ def test_two_pipelines_render_the_same_image_as_one(hpt, sio):
         b = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, samples_per_pass=4))           # 2 x 4 Mi slots
         c = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, samples_per_pass=3, flags=hpt.FLAG_RUSSIAN_ROULETTE))
         d = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_RUSSIAN_ROULETTE | hpt.FLAG_SINGLE_PIPELINE))
+        # a render that fits one pass (8 Mi slots; also an odd sample count) is cut into two concurrent half passes by
+        # default -- the share of one rank of a multi-GPU render is such a render
+        e = scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_TIME_KERNELS))
+        n_two = scene.stats()["n_shade"]
+        scene.render_pt(big, 1024, 1024, 4, 8, hpt.make_params(seed=2, flags=hpt.FLAG_TIME_KERNELS | hpt.FLAG_SINGLE_PIPELINE))
+        n_one = scene.stats()["n_shade"]
+        f = scene.render_pt(big, 1024, 1024, 4, 7, hpt.make_params(seed=2))
+        g = scene.render_pt(big, 1024, 1024, 4, 7, hpt.make_params(seed=2, flags=hpt.FLAG_SINGLE_PIPELINE))
     assert np.array_equal(a, b) and np.array_equal(c, d) and not np.array_equal(a, c)
+    assert np.array_equal(a, e) and np.array_equal(f, g) and n_two == 2 * n_one
 
 
 def test_bdpt_virtual_ranks_assemble_bitwise(hpt, sio, oracle_mod):
