@@ -28,6 +28,7 @@ FLAG_OUTPUT_SUM = 4
 FLAG_TIME_KERNELS = 8
 FLAG_RUSSIAN_ROULETTE = 16
 FLAG_SINGLE_PIPELINE = 32
+FLAG_NO_HOST_WAIT = 64
 
 
 class HptError(RuntimeError):

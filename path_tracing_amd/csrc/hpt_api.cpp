@@ -408,10 +408,11 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     // back on that pipeline's stream FIRST, then the host waits for one after the other, so the pipelines keep running
     // side by side while it does.  This is the one place where hpt_render_pt_device blocks the calling thread
     // (include/hpt.h); a scene without delta materials never gets here with a non-empty queue and pays one read-back.
+    const bool no_host_wait = (flags & HPT_FLAG_NO_HOST_WAIT) != 0;     // enqueue every tail iteration unseen
     auto tails = [&](int npipes) -> int {
         bool live[2] = { npipes > 0, npipes > 1 };
         for(int it = eye_depth; it < max_iters && (live[0] || live[1]); ++it){
-            const bool look = ((it - eye_depth) & 1) == 0;
+            const bool look = !no_host_wait && ((it - eye_depth) & 1) == 0;
             if(look) for(int k = 0; k < npipes; ++k) if(live[k])
                 HIP_TRY(hipMemcpyAsync(pipe[k].h_count, &pipe[k].qcnt[it], sizeof(uint32_t), hipMemcpyDeviceToHost, pipe[k].st));
             for(int k = 0; k < npipes; ++k){

@@ -606,3 +606,33 @@ def test_many_materials_and_lights_beyond_the_lds_staging(hpt, sio, oracle_mod):
         fast = scene.render_pt(cam, W, H, depth, spp, hpt.make_params(seed=5))
     assert st["shadow_rays"] > 50_000 and gs["shadow_rays"] == st["shadow_rays"]
     assert np.array_equal(img, ref) and np.array_equal(fast, ref)
+
+
+def test_no_host_wait_only_enqueues(hpt, sio):
+    """HPT_FLAG_NO_HOST_WAIT: the device render call enqueues every tail iteration unseen and returns while the device
+    is still at work, on a scene whose mirror wall keeps paths alive past eye_depth (the default looks at a counter
+    every other tail iteration and so holds the calling thread for most of the render); same image."""
+    import time
+    import torch
+    L, sp, tr = sio.cornell_with_sphere(20000)
+    W = H = 1024
+    cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, W, H)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
+    with hpt.Scene(L, sp, tr) as scene:
+        images, host_ms, dev_ms = [], [], []
+        for flags in (0, hpt.FLAG_NO_HOST_WAIT):
+            p = hpt.make_params(seed=4, max_delta=12, flags=flags)
+            scene.render_pt_device(cam, W, H, 4, 32, p, out.data_ptr(), stream)          # warm-up: workspace allocation
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            scene.render_pt_device(cam, W, H, 4, 32, p, out.data_ptr(), stream)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            images.append(out.cpu().numpy().copy()); host_ms.append((t1 - t0) * 1e3); dev_ms.append((t2 - t0) * 1e3)
+    assert np.array_equal(images[0], images[1])
+    assert images[0].mean() > 0
+    # the blind render returns in a fraction of the time the device needs; the default held the thread for most of it
+    assert host_ms[1] < 0.35 * dev_ms[1], (host_ms, dev_ms)
+    assert host_ms[0] > 0.5 * dev_ms[0], (host_ms, dev_ms)
