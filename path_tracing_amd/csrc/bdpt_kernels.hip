@@ -650,17 +650,19 @@ HPT_DEV float bd_mis_weight(const BdptPathBuf &bp, uint32_t path, uint32_t slots
 }
 
 // connection loop body, src/cpu_bdpt.cpp:389-439.  A workgroup takes 4 (eye vertex, 64 light vertices)
-// tiles = 256 candidate pairs.  Phase 1: every lane runs the cheap culls of its pair (zero throughput,
-// distance, both cosines, emission cone) and the survivors are compacted into an LDS list (ballot +
-// mbcnt); culled pairs get their zero written at once.  Phase 2: the expensive part -- two BSDF values,
-// the shadow ray, the MIS weight -- runs over the dense survivor list, so its lanes are all busy.  Frames,
-// local directions, Lambda terms and diffuse lobes come from the per-vertex contexts.
+// tiles = 256 candidate pairs per trip.  Phase 1: every lane runs the cheap culls of its pair (zero throughput,
+// distance, both cosines, emission cone); culled pairs get their zero written at once, the survivors go onto an
+// LDS list (ballot + mbcnt).  Phase 2: the expensive part -- two BSDF values, the shadow ray, the MIS weight --
+// runs over that list 256 pairs at a time: the list is kept ACROSS trips and evaluated only when it holds a full
+// workgroup of pairs (and once at the end), so every wave of phase 2 has all its lanes busy whatever fraction of
+// the candidates survives.  The table is indexed by (vertex, light vertex), so the order of evaluation is free.
+// Frames, local directions, Lambda terms and diffuse lobes come from the per-vertex contexts.
 __global__ __launch_bounds__(kBlock)
 void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lvs, const LightVertexCtx *lctx, int n_lv,
                     int light_depth, const uint32_t *cqueue, const uint32_t *ccount, uint32_t slots){
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
-    __shared__ uint32_t s_pair_path[kBlock];
-    __shared__ uint32_t s_pair_j[kBlock];
+    __shared__ uint32_t s_pair_path[2 * kBlock];
+    __shared__ uint32_t s_pair_j[2 * kBlock];
     __shared__ uint32_t s_n;
     uint32_t *stk = s_stack + threadIdx.x;
     uint32_t count = *ccount;
@@ -668,9 +670,46 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
     unsigned long long items = (unsigned long long) count * chunks;
     uint32_t wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     unsigned long long groups = (items + 3ull) / 4ull;
+    // phase 2 for one surviving pair
+    auto evaluate = [&](uint32_t path, int j){
+        float4 vp = bp.vtx_pos[path], vn = bp.vtx_nrm[path], vt = bp.vtx_thr[path], vw = bp.vtx_wo[path], vb = bp.vtx_base[path];
+        const LightVertexDev lv = lvs[j];
+        const LightVertexCtx *lcp = lctx + j;
+        f3 v_pos = xyz(vp), v_n = xyz(vn), v_thr = xyz(vt);
+        Mat vm; vm.base = xyz(vb); vm.roughness = vp.w; vm.metallic = vn.w; vm.eta = vt.w;
+        int depth = (int) f2u(vw.w);
+        f3 lthr = ld3(lv.thr);
+        f3 d_vec = ld3(lv.pos) - v_pos;
+        float dist2 = dot3(d_vec, d_vec);
+        float dist = sqrtf(dist2);
+        f3 wi = d_vec / dist;
+        float cosE = fmaxf(0.0f, dot3(v_n, wi));
+        float cosL = fmaxf(0.0f, dot3(ld3(lv.normal), wi * -1.0f));
+        int t_idx = j % light_depth;
+        f3 contrib = mk3(0, 0, 0);
+        f3 fE; float pdf_unused;
+        { ShadeCtx ce; ShadePre pe;
+          load_eye_value_ctx(bp, path, slots, v_n, ce, pe);
+          bsdf_eval_pdf<true, false>(vm, ce, wi, fE, pdf_unused, &pe); }
+        f3 fL = mk3(1.0f, 1.0f, 1.0f);
+        if(!(lv.flags & 1u) && t_idx > 0){
+            ShadeCtx cl; cl.T = ld3(lcp->T); cl.B = ld3(lcp->B); cl.N = ld3(lv.normal); cl.wo = ld3(lcp->wo_l);
+            ShadePre pl; pl.lam_o = lcp->lam_l; pl.diffuse = ld3(lcp->diffuse);
+            bsdf_eval_pdf<true, false>(lv_mat(lv), cl, wi * -1.0f, fL, pdf_unused, &pl);
+        }
+        bool ok = !((fE.x <= 0.0f && fE.y <= 0.0f && fE.z <= 0.0f) || (fL.x <= 0.0f && fL.y <= 0.0f && fL.z <= 0.0f));
+        if(ok && bd_visible(sc, v_pos + v_n * kEps, ld3(lv.pos) + ld3(lv.normal) * kEps, stk)){
+            float G = (cosE * cosL) / fmaxf(dist2, 1e-4f);
+            const size_t first = (size_t) (j / light_depth) * light_depth;
+            float mis_w = bd_mis_weight(bp, path, slots, depth, vm, lvs + first, lcp, t_idx, d_vec, dist2);
+            f3 c = v_thr * fE * G * fL * lthr * mk3(1.0f, 1.0f, 1.0f) * mis_w;
+            if(is_valid_color(c)) contrib = clamp_radiance(c, 15.0f);
+        }
+        bp.contrib[(size_t) path * n_lv + j] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+    };
+    if(threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
     for(unsigned long long gidx = blockIdx.x; gidx < groups; gidx += gridDim.x){
-        if(threadIdx.x == 0) s_n = 0u;
-        __syncthreads();
         // ---- phase 1: culls ----
         unsigned long long w = gidx * 4ull + wave_in_block;
         bool survive = false;
@@ -702,50 +741,22 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
                 if(!ok) bp.contrib[(size_t) path * n_lv + j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         }
+        // the list holds fewer than kBlock pairs here and gains at most kBlock
         uint32_t pos = lds_push(survive, &s_n);
         if(survive){ s_pair_path[pos] = path; s_pair_j[pos] = (uint32_t) j; }
         __syncthreads();
-        // ---- phase 2: dense evaluation of the survivors ----
+        // ---- phase 2: a full workgroup of survivors, taken from the top of the list ----
         uint32_t n = s_n;
-        if(threadIdx.x < n){
-            path = s_pair_path[threadIdx.x]; j = (int) s_pair_j[threadIdx.x];
-            float4 vp = bp.vtx_pos[path], vn = bp.vtx_nrm[path], vt = bp.vtx_thr[path], vw = bp.vtx_wo[path], vb = bp.vtx_base[path];
-            const LightVertexDev lv = lvs[j];
-            const LightVertexCtx *lcp = lctx + j;
-            f3 v_pos = xyz(vp), v_n = xyz(vn), v_thr = xyz(vt);
-            Mat vm; vm.base = xyz(vb); vm.roughness = vp.w; vm.metallic = vn.w; vm.eta = vt.w;
-            int depth = (int) f2u(vw.w);
-            f3 lthr = ld3(lv.thr);
-            f3 d_vec = ld3(lv.pos) - v_pos;
-            float dist2 = dot3(d_vec, d_vec);
-            float dist = sqrtf(dist2);
-            f3 wi = d_vec / dist;
-            float cosE = fmaxf(0.0f, dot3(v_n, wi));
-            float cosL = fmaxf(0.0f, dot3(ld3(lv.normal), wi * -1.0f));
-            int t_idx = j % light_depth;
-            f3 contrib = mk3(0, 0, 0);
-            f3 fE; float pdf_unused;
-            { ShadeCtx ce; ShadePre pe;
-              load_eye_value_ctx(bp, path, slots, v_n, ce, pe);
-              bsdf_eval_pdf<true, false>(vm, ce, wi, fE, pdf_unused, &pe); }
-            f3 fL = mk3(1.0f, 1.0f, 1.0f);
-            if(!(lv.flags & 1u) && t_idx > 0){
-                ShadeCtx cl; cl.T = ld3(lcp->T); cl.B = ld3(lcp->B); cl.N = ld3(lv.normal); cl.wo = ld3(lcp->wo_l);
-                ShadePre pl; pl.lam_o = lcp->lam_l; pl.diffuse = ld3(lcp->diffuse);
-                bsdf_eval_pdf<true, false>(lv_mat(lv), cl, wi * -1.0f, fL, pdf_unused, &pl);
-            }
-            bool ok = !((fE.x <= 0.0f && fE.y <= 0.0f && fE.z <= 0.0f) || (fL.x <= 0.0f && fL.y <= 0.0f && fL.z <= 0.0f));
-            if(ok && bd_visible(sc, v_pos + v_n * kEps, ld3(lv.pos) + ld3(lv.normal) * kEps, stk)){
-                float G = (cosE * cosL) / fmaxf(dist2, 1e-4f);
-                const size_t first = (size_t) (j / light_depth) * light_depth;
-                float mis_w = bd_mis_weight(bp, path, slots, depth, vm, lvs + first, lcp, t_idx, d_vec, dist2);
-                f3 c = v_thr * fE * G * fL * lthr * mk3(1.0f, 1.0f, 1.0f) * mis_w;
-                if(is_valid_color(c)) contrib = clamp_radiance(c, 15.0f);
-            }
-            bp.contrib[(size_t) path * n_lv + j] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+        if(n >= (uint32_t) kBlock){
+            uint32_t e = n - (uint32_t) kBlock + threadIdx.x;
+            evaluate(s_pair_path[e], (int) s_pair_j[e]);
+            __syncthreads();
+            if(threadIdx.x == 0) s_n = n - (uint32_t) kBlock;
+            __syncthreads();
         }
-        __syncthreads();
     }
+    uint32_t n = s_n;
+    if(threadIdx.x < n) evaluate(s_pair_path[threadIdx.x], (int) s_pair_j[threadIdx.x]);
 }
 
 // total_L of one eye vertex: the table row summed in light-vertex order (the CPU loop's order, so the
@@ -830,7 +841,7 @@ void launch_bdpt_connect(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, Bdpt
     unsigned long long waves = (unsigned long long) max_items * (((unsigned) n_lv + 63u) / 64u);
     unsigned long long g = (waves + (kBlock / 64) - 1) / (kBlock / 64);
     if(g < 1ull) g = 1ull;
-    if(g > 16384ull) g = 16384ull;
+    if(g > 4096ull) g = 4096ull;            // several trips per workgroup: the survivor list fills up across them
     hipLaunchKernelGGL(k_bdpt_connect, dim3((uint32_t) g), dim3(kBlock), 0, s, sc, pb, bp, lv, lctx, n_lv, light_depth, cqueue, ccount,
                        slots);
 }
