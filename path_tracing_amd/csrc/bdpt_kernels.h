@@ -14,7 +14,7 @@ struct BdptSceneDev {
     const DevGroup *groups;
     const DevMaterial *mats;
     const DevLight *lights;
-    int num_groups, num_lights, num_mats, pad;
+    int num_groups, num_lights, num_mats, stack_levels;   // stack_levels: deepest group tree (traversal stack entries per lane)
     float scene_min[3], scene_max[3];
 };
 

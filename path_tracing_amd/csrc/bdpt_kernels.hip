@@ -660,11 +660,11 @@ HPT_DEV float bd_mis_weight(const BdptPathBuf &bp, uint32_t path, uint32_t slots
 __global__ __launch_bounds__(kBlock)
 void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lvs, const LightVertexCtx *lctx, int n_lv,
                     int light_depth, const uint32_t *cqueue, const uint32_t *ccount, uint32_t slots){
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    extern __shared__ uint32_t s_dyn_stack[];          // [stack level][lane], sized by the scene's deepest group tree
     __shared__ uint32_t s_pair_path[2 * kBlock];
     __shared__ uint32_t s_pair_j[2 * kBlock];
     __shared__ uint32_t s_n;
-    uint32_t *stk = s_stack + threadIdx.x;
+    uint32_t *stk = s_dyn_stack + threadIdx.x;
     uint32_t count = *ccount;
     uint32_t chunks = ((uint32_t) n_lv + 63u) / 64u;
     unsigned long long items = (unsigned long long) count * chunks;
@@ -842,7 +842,8 @@ void launch_bdpt_connect(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, Bdpt
     unsigned long long g = (waves + (kBlock / 64) - 1) / (kBlock / 64);
     if(g < 1ull) g = 1ull;
     if(g > 4096ull) g = 4096ull;            // several trips per workgroup: the survivor list fills up across them
-    hipLaunchKernelGGL(k_bdpt_connect, dim3((uint32_t) g), dim3(kBlock), 0, s, sc, pb, bp, lv, lctx, n_lv, light_depth, cqueue, ccount,
+    const size_t stack_bytes = (size_t) (sc.stack_levels > 0 ? sc.stack_levels : kStackDepth) * kBlock * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_bdpt_connect, dim3((uint32_t) g), dim3(kBlock), stack_bytes, s, sc, pb, bp, lv, lctx, n_lv, light_depth, cqueue, ccount,
                        slots);
 }
 void launch_bdpt_reduce(hipStream_t s, PathBuf pb, BdptPathBuf bp, int n_lv, const uint32_t *cqueue, const uint32_t *ccount,

@@ -562,7 +562,8 @@ int ensure_bdpt_scene(hpt_scene *s){
     if(e != hipSuccess) return fail(HPT_ERR_DEVICE, std::string("bdpt scene upload: ") + hipGetErrorString(e));
     s->bd.nodes = (const float4 *) s->bd_nodes; s->bd.tris = (const float4 *) s->bd_tris; s->bd.spheres = s->bd_spheres;
     s->bd.groups = s->bd_groups; s->bd.mats = s->bd_mats; s->bd.lights = s->bd_lights;
-    s->bd.num_groups = (int) hb.groups.size(); s->bd.num_lights = s->nl; s->bd.num_mats = (int) hb.materials.size(); s->bd.pad = 0;
+    s->bd.num_groups = (int) hb.groups.size(); s->bd.num_lights = s->nl; s->bd.num_mats = (int) hb.materials.size();
+    s->bd.stack_levels = std::min(std::max(hb.bvh_depth, 1) + 1, kStackDepth);
     for(int a = 0; a < 3; ++a){ s->bd.scene_min[a] = hb.scene_min[a]; s->bd.scene_max[a] = hb.scene_max[a]; }
     s->bd_ready = true;
     return HPT_OK;
