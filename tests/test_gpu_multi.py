@@ -199,3 +199,22 @@ def test_library_and_torch_share_one_hip_runtime_whatever_the_import_order():
     run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stderr
     assert "OK 4.0 True 1" in run.stdout
+
+
+def test_bench_self_spawned_ranks_share_the_gpu():
+    """`python bench.py --gpus 2` as the driver invokes it (no launcher): the two ranks are child processes of
+    torch.distributed.run, here with gloo because an RCCL communicator refuses two ranks on one device; every rank
+    renders its tiles on the GPU, rank 0 gathers, un-tiles, checks the image and prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "256",
+                          "--spp", "16", "--tris", "5000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, run.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["exchange"]["ranks_in_communicator"] == 2 and out["exchange"]["backend"] == "gloo"
+    assert out["value"] > 0 and all(v is True for v in out["verify"].values()), out["verify"]
