@@ -314,6 +314,11 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "pipelines_in_flight": 1 if args.single_pipeline else 2,
                 "exclusive": excl_obj,
+                "round1_accounting": {
+                    "achieved": (bytes_per_launch + 32.0 * (boxes / 2.0) / max(launches_per_render, 1)) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else None,
+                    "frac": (bytes_per_launch + 32.0 * (boxes / 2.0) / max(launches_per_render, 1)) / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_launch_ms > 0 else None,
+                    "note": "for comparison with BENCH_r01 only: round 1's line billed 32 B per child box, i.e. 64 B per node visit (SURVEY 8d says 32 B per node); "
+                            "its 0.81 is on that scale, and on a tree that needed 1.7 x the tests per ray"},
                 "note": "rank 0's kernels; bytes = 32*nodes visited + 36*tris + 44*closest rays + 36*shadow rays of this rank (SURVEY 8d). "
                         "Two passes of a render are in flight on two streams, so a launch shares the device with the other pipeline's kernels "
                         "and its duration (hence `achieved`) is that of a shared device; `exclusive` has the single-pipeline figures."}
