@@ -53,7 +53,8 @@ struct BdptPathBuf {
     float4 *vtx_base;         // material base colour xyz | unused
     float4 *hist_pos_eta;     // [depth][slot]: vertex position xyz | material eta
     float2 *hist_pdf;         // [depth][slot]: pdf_fwd, pdf_rev (final values)
-    float4 *contrib;          // [slot][light vertex]: clamped contribution xyz | unused
+    float4 *contrib;          // [slot][light vertex]: clamped contribution xyz | unused; written for the pairs that pass the culls only
+    unsigned long long *valid; // [slot][64-vertex chunk]: bit j = pair (slot, chunk * 64 + j) passed the culls and has a table entry
     float4 *ectx;             // [7][slot]: the eye vertex's shading contexts (k_bdpt_vertex): frame of the normal, wo in it,
                               // Lambda(wo), diffuse lobe | normalize(normal), its frame, the MIS direction in it, its Lambda
 };

@@ -738,8 +738,11 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
                     if(dot3(light_dir, wi * -1.0f) < L.cos_cutoff) ok = false;
                 }
                 survive = ok;
-                if(!ok) bp.contrib[(size_t) path * n_lv + j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
+            // one 64-bit word per (vertex, chunk) says which pairs get a table entry; a culled pair gets none (its
+            // contribution is zero and k_bdpt_reduce never reads it)
+            unsigned long long vm = __ballot(survive);
+            if(lane == 0u) bp.valid[(size_t) path * chunks + (uint32_t) (w % chunks)] = vm;
         }
         // the list holds fewer than kBlock pairs here and gains at most kBlock
         uint32_t pos = lds_push(survive, &s_n);
@@ -774,15 +777,22 @@ void k_bdpt_reduce(PathBuf pb, BdptPathBuf bp, int n_lv, const uint32_t *cqueue,
         uint32_t mine = base + lane;
         uint32_t my_path = mine < count ? cqueue[mine] : 0u;
         f3 total = mk3(0, 0, 0);
+        const uint32_t chunks = ((uint32_t) n_lv + 63u) / 64u;
+        unsigned long long my_valid = 0ull;
         for(int e0 = 0; e0 < n_lv; e0 += kRedEntries){
+            // which of this vertex's pairs have a table entry (the others were culled: exact zeros, adding them changes nothing)
+            if((e0 & 63) == 0) my_valid = mine < count ? bp.valid[(size_t) my_path * chunks + (uint32_t) (e0 >> 6)] : 0ull;
+            const uint32_t mb = (uint32_t) (my_valid >> (e0 & 63)) & 0xFFu;
+            if(__ballot(mb != 0u) == 0ull) continue;                    // none of the wave's 64 vertices has an entry in this group
             // 8 loads: lanes (v = it * 8 + lane / 8, e = lane % 8)
 #pragma unroll
             for(int it = 0; it < 8; ++it){
                 uint32_t v = (uint32_t) it * 8u + (lane >> 3);
                 int e = e0 + (int) (lane & 7u);
                 uint32_t vp = (uint32_t) __shfl((int) my_path, (int) v, 64);
+                uint32_t vb = (uint32_t) __shfl((int) mb, (int) v, 64);
                 float4 val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if(base + v < count && e < n_lv) val = bp.contrib[(size_t) vp * n_lv + e];
+                if((vb >> (lane & 7u)) & 1u) val = bp.contrib[(size_t) vp * n_lv + e];
                 s_tile[wave][v][lane & 7u] = val;
             }
             __builtin_amdgcn_wave_barrier();

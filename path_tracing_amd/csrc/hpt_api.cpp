@@ -107,7 +107,7 @@ struct hpt_scene {
     BdptSceneDev bd{};
     BvhNode *bd_nodes = nullptr; DevTriangle *bd_tris = nullptr; DevRound *bd_spheres = nullptr; DevGroup *bd_groups = nullptr;
     DevMaterial *bd_mats = nullptr; DevLight *bd_lights = nullptr;
-    BdptPathBuf bp{}; size_t bd_cap_slots = 0, bd_cap_hist = 0, bd_cap_contrib = 0;
+    BdptPathBuf bp{}; size_t bd_cap_slots = 0, bd_cap_hist = 0, bd_cap_contrib = 0, bd_cap_valid = 0;
     LightVertexDev *d_lv = nullptr; size_t bd_cap_lv = 0;
     LightVertexCtx *d_lctx = nullptr; size_t bd_cap_lctx = 0;
     uint32_t *cqueue = nullptr; size_t bd_cap_cqueue = 0;
@@ -537,11 +537,11 @@ void free_bdpt_scene(hpt_scene *s){
 void free_bdpt(hpt_scene *s){
     free_bdpt_scene(s);
     hipFree(s->bp.last_pos_pdf); hipFree(s->bp.last_normal); hipFree(s->bp.vtx_pos); hipFree(s->bp.vtx_nrm); hipFree(s->bp.vtx_thr);
-    hipFree(s->bp.vtx_wo); hipFree(s->bp.vtx_base); hipFree(s->bp.hist_pos_eta); hipFree(s->bp.hist_pdf); hipFree(s->bp.contrib);
+    hipFree(s->bp.vtx_wo); hipFree(s->bp.vtx_base); hipFree(s->bp.hist_pos_eta); hipFree(s->bp.hist_pdf); hipFree(s->bp.contrib); hipFree(s->bp.valid);
     hipFree(s->bp.ectx);
     hipFree(s->d_lv); hipFree(s->d_lctx); hipFree(s->cqueue);
     s->bp = BdptPathBuf{}; s->d_lv = nullptr; s->d_lctx = nullptr; s->cqueue = nullptr;
-    s->bd_cap_slots = s->bd_cap_hist = s->bd_cap_contrib = s->bd_cap_lv = s->bd_cap_lctx = s->bd_cap_cqueue = 0;
+    s->bd_cap_slots = s->bd_cap_hist = s->bd_cap_contrib = s->bd_cap_valid = s->bd_cap_lv = s->bd_cap_lctx = s->bd_cap_cqueue = 0;
 }
 
 int ensure_bdpt_scene(hpt_scene *s){
@@ -631,7 +631,7 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
         c = s->bd_cap_slots; rc = grow(&s->bp.vtx_base, c, slots); if(rc) return rc;
         c = s->bd_cap_slots * 7; rc = grow(&s->bp.ectx, c, slots * 7); if(rc) return rc;
         s->bd_cap_slots = slots;
-        s->bd_cap_hist = 0; s->bd_cap_contrib = 0;
+        s->bd_cap_hist = 0; s->bd_cap_contrib = 0; s->bd_cap_valid = 0;
     }
     rc = grow(&s->cqueue, s->bd_cap_cqueue, slots); if(rc) return rc;
     { size_t need = slots * (size_t) eye_depth;
@@ -642,6 +642,7 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
           s->bd_cap_hist = need;
       } }
     rc = grow(&s->bp.contrib, s->bd_cap_contrib, slots * (size_t) std::max(n_lv, 1)); if(rc) return rc;
+    rc = grow(&s->bp.valid, s->bd_cap_valid, slots * (size_t) ((std::max(n_lv, 1) + 63) / 64)); if(rc) return rc;
     rc = grow(&s->d_lv, s->bd_cap_lv, (size_t) std::max(n_lv, 1)); if(rc) return rc;
     rc = grow(&s->d_lctx, s->bd_cap_lctx, (size_t) std::max(n_lv, 1)); if(rc) return rc;
 
