@@ -74,7 +74,7 @@ typedef struct hpt_params {
                                       * bounce, so images differ from the roulette-free ones sample by sample */
 #define HPT_FLAG_SINGLE_PIPELINE 32 /* PT: one pass in flight at a time (default: two passes of a render run
                                       * concurrently on two streams with a workspace each; same image) */
-#define HPT_FLAG_NO_HOST_WAIT 64    /* PT: hpt_render_pt_device never waits for the device.  Every iteration up to
+#define HPT_FLAG_NO_HOST_WAIT 64    /* hpt_render_pt_device / hpt_render_bdpt_device never wait for the device.  Every iteration up to
                                       * eye_depth + max_delta is enqueued whether or not a path is still alive (a
                                       * kernel that finds its queue empty returns at once, but its grid is sized for a
                                       * full queue: ~0.24 ms per unused iteration of a 128 Mi-slot pass; config 3 with

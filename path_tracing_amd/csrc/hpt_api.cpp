@@ -671,7 +671,9 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
             int cur = 0;
             for(int it = 0; it < max_iters; ++it){
                 const int ci = it;                             // counter slot of this iteration
-                if(it >= eye_depth){
+                // past eye_depth only paths on free delta bounces are alive: the host looks every other iteration (an
+                // iteration on an empty queue costs four empty launches), or never with HPT_FLAG_NO_HOST_WAIT
+                if(it >= eye_depth && !(P.flags & HPT_FLAG_NO_HOST_WAIT) && ((it - eye_depth) & 1) == 0){
                     HIP_TRY(hipMemcpyAsync(s->pass[0].h_count, &qcnt[ci], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipStreamSynchronize(stream));
                     if(*s->pass[0].h_count == 0u) break;

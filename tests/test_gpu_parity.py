@@ -633,6 +633,15 @@ def test_no_host_wait_only_enqueues(hpt, sio):
             images.append(out.cpu().numpy().copy()); host_ms.append((t1 - t0) * 1e3); dev_ms.append((t2 - t0) * 1e3)
     assert np.array_equal(images[0], images[1])
     assert images[0].mean() > 0
+    # the bidirectional estimator honours the flag too (glass and mirror spheres of input.txt: tail iterations exist)
+    sc = sio.load_scene(os.path.join(GOLDEN, "scenes", "input.txt"))
+    Lb, spb, trb = sio.flatten_for_pt(sc)
+    camb = sio.camera_for(sc, 96, 64)
+    with hpt.Scene(Lb, spb, trb) as scene:
+        scene.set_groups(*sio.object_order(sc))
+        a = scene.render_bdpt(camb, 96, 64, 4, 4, 3, 4, hpt.make_params(seed=6, max_delta=6))
+        b = scene.render_bdpt(camb, 96, 64, 4, 4, 3, 4, hpt.make_params(seed=6, max_delta=6, flags=hpt.FLAG_NO_HOST_WAIT))
+    assert np.array_equal(a, b) and a.mean() > 0
     # the blind render returns in a fraction of the time the device needs; the default held the thread for most of it
     assert host_ms[1] < 0.35 * dev_ms[1], (host_ms, dev_ms)
     assert host_ms[0] > 0.5 * dev_ms[0], (host_ms, dev_ms)
