@@ -343,3 +343,47 @@ def test_cli_gpus_flag_fans_out_inside_the_blocking_call(tmp_path, hpt):
     # more devices than the node has: reported, no image
     run = subprocess.run([cli, "--input", scene, "--output", str(tmp_path / "x.pfm"), "--spp", "1", "--gpus", str(n + 1)], capture_output=True, text=True)
     assert "device id outside" in run.stderr
+
+
+def test_parser_survives_mutated_inputs(tmp_path):
+    """The mapped-file tokenizer reads whatever bytes it is given: 300 mutated copies of the reference's scene files and
+    of an OBJ snippet (deleted spans, injected tags and malformed numbers, random bytes, truncation) go through the scene
+    and the OBJ reader in a child process, which must neither crash nor hang."""
+    import random
+    import subprocess
+    import sys
+    rng = random.Random(5)
+    seeds = [open(os.path.join(GOLDEN, "scenes", f), "rb").read() for f in ("input.txt", "mis_test.txt")]
+    seeds.append(b"v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2 3 4\nf 1/1/1 2/2/2 3/3/3\nf -1 -2 -3\n")
+    tokens = [b"T", b"S", b"L", b"M", b"R", b"E", b"V", b"U", b"F", b"G", b"v", b"f", b"#", b"-", b"1e40", b"nan", b"inf", b"-0", b"1e-50",
+              b"0x10", b"+5", b".", b"e", b"1.2.3", b"999999999999999999999", b"-2147483649", b"/", b"//", b"1//2", b"\t", b"\r\n", b"\x00", b"\xff"]
+
+    def mutate(b):
+        b = bytearray(b)
+        for _ in range(rng.randint(1, 8)):
+            op = rng.randint(0, 5)
+            pos = rng.randint(0, max(0, len(b) - 1)) if b else 0
+            if op == 0 and b:
+                del b[pos:pos + rng.randint(1, 40)]
+            elif op == 1:
+                b[pos:pos] = rng.choice(tokens) + b" "
+            elif op == 2 and b:
+                b[pos] = rng.randint(0, 255)
+            elif op == 3:
+                b[pos:pos] = bytes(rng.randint(0, 255) for _ in range(rng.randint(1, 10)))
+            elif op == 4 and b:
+                b = b[:pos]
+            else:
+                b[pos:pos] = b"\n" + rng.choice(tokens) + b" " + b" ".join(rng.choice(tokens) for _ in range(rng.randint(0, 12))) + b"\n"
+        return bytes(b)
+
+    paths = []
+    for k in range(300):
+        p = tmp_path / ("m%d.txt" % k)
+        p.write_bytes(mutate(rng.choice(seeds)) if k % 10 else bytes(rng.randint(0, 255) for _ in range(rng.randint(0, 300))))
+        paths.append(str(p))
+    child = ("import sys\nsys.path.insert(0, %r)\nfrom path_tracing_amd import scene_io as S\n"
+             "for p in sys.argv[1:]:\n    for obj in (False, True):\n        try:\n            S.load_scene_fast(p, obj=obj, W=16, H=8)\n"
+             "        except IOError:\n            pass\nprint('survived')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-c", child] + paths, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "survived" in run.stdout, (run.returncode, run.stderr[-500:])
