@@ -74,13 +74,15 @@ typedef struct hpt_params {
                                       * bounce, so images differ from the roulette-free ones sample by sample */
 #define HPT_FLAG_SINGLE_PIPELINE 32 /* PT: one pass in flight at a time (default: two passes of a render run
                                       * concurrently on two streams with a workspace each; same image) */
-#define HPT_FLAG_NO_HOST_WAIT 64    /* hpt_render_pt_device / hpt_render_bdpt_device never wait for the device.  Every iteration up to
-                                      * eye_depth + max_delta is enqueued whether or not a path is still alive (a
-                                      * kernel that finds its queue empty returns at once, but its grid is sized for a
-                                      * full queue: ~0.24 ms per unused iteration of a 128 Mi-slot pass; config 3 with
-                                      * the default max_delta of 64, of which it needs 4: 132 -> 160 ms), so give
-                                      * max_delta the value the scene needs.  Same image.  Default off: the host looks
-                                      * at a 4-byte counter every other tail iteration instead */
+#define HPT_FLAG_NO_HOST_WAIT 64    /* hpt_render_pt_device / hpt_render_bdpt_device never wait for the device.  Every
+                                      * iteration up to eye_depth + max_delta is enqueued whether or not a path is still
+                                      * alive; the iterations past eye_depth get a small fixed grid (8 workgroups per CU,
+                                      * the kernels walk their queue with a stride), so one that finds its queue empty
+                                      * costs a few microseconds: config 3 with the default max_delta of 64, of which it
+                                      * needs 4, renders in the same 131 ms either way.  What it costs is a fixed ~200
+                                      * launches per pass, i.e. about a millisecond on a render of a few milliseconds --
+                                      * hence opt-in; the default looks at a 4-byte counter every other tail iteration.
+                                      * Same image */
 
 typedef struct hpt_stats {
     uint64_t samples;         /* camera samples traced by the last render */
@@ -137,8 +139,8 @@ int hpt_render_pt(hpt_scene *scene, const void *camera, int W, int H,
  * free delta bounces (mirror, glass: reference src/pt_cu.cu:228) need further iterations whose number only the
  * device knows, and for those the calling thread waits on a 4-byte read-back every other iteration -- i.e. on
  * scenes with delta materials the call MAY BLOCK THE HOST for most of the render's duration.  It never blocks
- * the device: both pipelines of a render keep running while the host waits.  HPT_FLAG_NO_HOST_WAIT trades the
- * read-backs for blind launches: the call then only enqueues. */
+ * the device: both pipelines of a render keep running while the host waits.  With HPT_FLAG_NO_HOST_WAIT the call
+ * only enqueues (blind launches instead of read-backs). */
 int hpt_render_pt_device(hpt_scene *scene, const void *camera, int W, int H,
                          int eye_depth, int spp, const hpt_params *params,
                          void *d_local, void *hip_stream);

@@ -375,9 +375,14 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         }
         return HPT_OK;
     };
+    // HPT_FLAG_NO_HOST_WAIT enqueues the iterations past eye_depth without knowing whether a path is left: those launches
+    // get a grid of 8 workgroups per CU instead of one sized for a full queue (an empty launch then costs a few
+    // microseconds instead of ~80), and the kernels walk the chunks of whatever the queue holds with a stride
+    const uint32_t blind_groups = (flags & HPT_FLAG_NO_HOST_WAIT) ? (uint32_t) std::max(s->num_cus, 1) * 8u : 0u;
     auto iteration = [&](Pass &q, int it){
         const uint32_t *eq = it == 0 ? nullptr : q.queue[q.cur];
         const PrimaryGen *primary = (it == 0 && in_flight_primaries) ? &q.primary : nullptr;
+        const uint32_t cap = it >= eye_depth ? blind_groups : 0u;
         if(legacy){
             LaunchTimer t(s, q.st, timek, 0);
             launch_extend(q.st, s->sd, q.pb, eq, &q.qcnt[it], q.slots, kflags, wc);
@@ -386,7 +391,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
             TraceSplit split{ q.lqueue[0], &q.lecnt[it], q.lqueue[1], &q.lscnt[it], budget };
             { LaunchTimer t(s, q.st, timek, 0);
               launch_trace(q.st, s->sd, q.pb, q.sb, eq, &q.qcnt[it], q.slots, q.squeue,
-                           q.pending_shadow >= 0 ? &q.scnt[q.pending_shadow] : nullptr, q.slots, s->stack_levels, kflags, tuning, wc, &split, primary); }
+                           q.pending_shadow >= 0 ? &q.scnt[q.pending_shadow] : nullptr, q.slots, s->stack_levels, kflags, tuning, wc, &split, primary, cap); }
             if(split.budget > 0){
                 LaunchTimer t(s, q.st, timek, 4);
                 launch_trace_resume(q.st, s->sd, q.pb, q.sb, true, q.pending_shadow >= 0, q.slots, s->stack_levels, wc, split, primary);
@@ -395,7 +400,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         }
         { LaunchTimer t(s, q.st, timek, 1);
           launch_shade(q.st, s->sd, q.pb, eq, &q.qcnt[it], q.slots, q.queue[q.cur ^ 1],
-                       &q.qcnt[it + 1], q.sb, q.squeue, &q.scnt[it], eye_depth, P.max_delta, roulette, wc, primary); }
+                       &q.qcnt[it + 1], q.sb, q.squeue, &q.scnt[it], eye_depth, P.max_delta, roulette, wc, primary, cap); }
         if(legacy){
             LaunchTimer t(s, q.st, timek, 2);
             launch_connect(q.st, s->sd, q.pb, q.sb, q.squeue, &q.scnt[it], q.slots, kflags, wc);
@@ -430,7 +435,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
             TraceSplit split{ q.lqueue[0], &q.lecnt[max_iters], q.lqueue[1], &q.lscnt[max_iters], budget };
             { LaunchTimer t(s, q.st, timek, 2);
               launch_trace(q.st, s->sd, q.pb, q.sb, nullptr, nullptr, 0, q.squeue, &q.scnt[q.pending_shadow], q.slots,
-                           s->stack_levels, kflags, tuning, wc, &split); }
+                           s->stack_levels, kflags, tuning, wc, &split, nullptr, blind_groups); }
             if(split.budget > 0){
                 LaunchTimer t(s, q.st, timek, 4);
                 launch_trace_resume(q.st, s->sd, q.pb, q.sb, false, true, q.slots, s->stack_levels, wc, split);

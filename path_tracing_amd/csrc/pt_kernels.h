@@ -75,7 +75,8 @@ void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t
                    uint32_t max_items, int flags, WorkCounters *wc);
 void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
                   uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue,
-                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc, const PrimaryGen *primary = nullptr);
+                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc, const PrimaryGen *primary = nullptr,
+                  uint32_t max_groups = 0);        // max_groups != 0 caps the grid (the kernels walk their chunks with a stride)
 void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue,
                     const uint32_t *scount, uint32_t max_items, int flags, WorkCounters *wc);
 // merged closest-hit (equeue) + any-hit (squeue) launch; either queue may be absent (null count)
@@ -85,7 +86,7 @@ struct TraceSplit { uint32_t *equeue, *ecount, *squeue, *scount; int budget; };
 void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue,
                   const uint32_t *ecount, uint32_t max_extend, const uint32_t *squeue, const uint32_t *scount,
                   uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc,
-                  const TraceSplit *split = nullptr, const PrimaryGen *primary = nullptr);
+                  const TraceSplit *split = nullptr, const PrimaryGen *primary = nullptr, uint32_t max_groups = 0);
 void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
                          uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split,
                          const PrimaryGen *primary = nullptr);

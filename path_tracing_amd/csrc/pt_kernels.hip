@@ -318,7 +318,7 @@ constexpr int kNeeWords = 20;
 // 0-2 wo (local) | 3-5 wi (local) | 6 Lambda(wo) | 7 material index | 8-10 throughput | 11 pdf_light_dir |
 // 12-14 shadow segment start | 15-17 shadow segment end | 18 path slot | 19 light index | parallel << 31
 
-template <bool PRIMARY>
+template <bool PRIMARY, bool STRIDED>
 __global__ __launch_bounds__(kBlock)
 void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
              uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue, uint32_t *scount,
@@ -405,9 +405,17 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     uint32_t chunk = (count + kShadeTargetGroups - 1) / kShadeTargetGroups;
     chunk = (chunk + kBlock - 1) / kBlock * kBlock;
     chunk = chunk < (uint32_t) kBlock ? (uint32_t) kBlock : (chunk > (uint32_t) kShadeChunk ? (uint32_t) kShadeChunk : chunk);
-    uint32_t begin = blockIdx.x * chunk;
-    uint32_t end = begin + chunk < count ? begin + chunk : count;
     uint32_t iters = 0;
+    // one chunk per workgroup when the grid covers the queue (the usual launch); STRIDED: a smaller grid (the unseen
+    // tail iterations of HPT_FLAG_NO_HOST_WAIT) walks the chunks with a stride
+    for(uint32_t cb = blockIdx.x; (unsigned long long) cb * chunk < count; cb += gridDim.x){
+    if(STRIDED && cb != blockIdx.x){
+        __syncthreads();                                   // the previous chunk's lists have been copied out
+        if(threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    uint32_t begin = cb * chunk;
+    uint32_t end = begin + chunk < count ? begin + chunk : count;
     for(uint32_t base = begin; base < end; base += kBlock){
         uint32_t i = base + threadIdx.x;
         bool alive = false, nee = false;
@@ -633,7 +641,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
         uint32_t qpos = lds_push(alive, &s_cnt[0]);
         if(alive) s_next[qpos] = path;
     }
-    if(staged != 0u) flush_nee(staged);
+    if(staged != 0u){ flush_nee(staged); staged = 0u; }
     __syncthreads();
     if(threadIdx.x == 0){
         s_cnt[2] = s_cnt[0] ? atomicAdd(next_count, s_cnt[0]) : 0u;
@@ -642,6 +650,8 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
     __syncthreads();
     for(uint32_t k = threadIdx.x; k < s_cnt[0]; k += kBlock) next_queue[s_cnt[2] + k] = s_next[k];
     for(uint32_t k = threadIdx.x; k < s_cnt[1]; k += kBlock) squeue[s_cnt[3] + k] = s_shadow[k];
+    if(!STRIDED) break;
+    }
     if(wc){
         unsigned long long v = iters;
         for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -1158,16 +1168,21 @@ void launch_extend(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t
 
 void launch_shade(hipStream_t s, const SceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
                   uint32_t max_items, uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue,
-                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc, const PrimaryGen *primary){
+                  uint32_t *scount, int max_depth, int max_delta, int roulette, WorkCounters *wc, const PrimaryGen *primary,
+                  uint32_t max_groups){
     // enough workgroups for either chunking regime (see k_shade)
     uint32_t g = (max_items + kShadeChunk - 1) / kShadeChunk;
     if(g < (uint32_t) kShadeTargetGroups) g = (uint32_t) kShadeTargetGroups;
     uint32_t small = (max_items + kBlock - 1) / kBlock;
     if(small < g) g = small < 1u ? 1u : small;
+    const bool strided = max_groups != 0u && g > max_groups;        // the kernel then walks the chunks with a stride
+    if(strided) g = max_groups;
     PrimaryGen none{};
-    if(primary) hipLaunchKernelGGL((k_shade<true>), dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
+    if(primary) hipLaunchKernelGGL((k_shade<true, false>), dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
                                    next_count, sb, squeue, scount, max_depth, max_delta, roulette, wc, *primary);
-    else hipLaunchKernelGGL((k_shade<false>), dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
+    else if(strided) hipLaunchKernelGGL((k_shade<false, true>), dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
+                                        next_count, sb, squeue, scount, max_depth, max_delta, roulette, wc, none);
+    else hipLaunchKernelGGL((k_shade<false, false>), dim3(g), dim3(kBlock), 0, s, sc, pb, queue, qcount, next_queue,
                             next_count, sb, squeue, scount, max_depth, max_delta, roulette, wc, none);
 }
 
@@ -1184,7 +1199,7 @@ void launch_connect(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb,
 void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue,
                   const uint32_t *ecount, uint32_t max_extend, const uint32_t *squeue, const uint32_t *scount,
                   uint32_t max_shadow, int stack_levels, int flags, int tuning, WorkCounters *wc, const TraceSplit *split,
-                  const PrimaryGen *primary){
+                  const PrimaryGen *primary, uint32_t max_groups){
     uint32_t chunk = ((tuning >> 16) & 0xFF) ? (uint32_t) ((tuning >> 16) & 0xFF) * 256u : (uint32_t) kTraceChunk;
     int refill_min = ((tuning >> 8) & 0xFF) ? ((tuning >> 8) & 0xFF) : kRefillMin;
     int node_min = ((tuning >> 24) & 0x7F) ? ((tuning >> 24) & 0x7F) : kNodeMin;
@@ -1199,6 +1214,7 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
     };
     uint32_t g = (ecount ? groups(max_extend) : 0u) + (scount ? groups(max_shadow) : 0u);
     if(g == 0u) return;
+    if(max_groups != 0u && g > max_groups) g = max_groups;          // k_trace walks the chunks with a stride
     if(stack_levels < 1) stack_levels = 1;
     if(stack_levels > kStackDepth) stack_levels = kStackDepth;
     int stack_words = (stack_levels + 1) * kBlock;                            // + the spare level of the branch-free step
