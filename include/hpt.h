@@ -76,10 +76,13 @@ typedef struct hpt_params {
                                       * concurrently on two streams with a workspace each; same image) */
 #define HPT_FLAG_NO_HOST_WAIT 64    /* hpt_render_pt_device / hpt_render_bdpt_device never wait for the device.  Every
                                       * iteration up to eye_depth + max_delta is enqueued whether or not a path is still
-                                      * alive; the iterations past eye_depth get a small fixed grid (8 workgroups per CU,
-                                      * the kernels walk their queue with a stride), so one that finds its queue empty
-                                      * costs a few microseconds: config 3 with the default max_delta of 64, of which it
-                                      * needs 4, renders in the same 131 ms either way.  What it costs is a fixed ~200
+                                      * alive; the iterations past eye_depth get small fixed grids (8 workgroups per CU;
+                                      * the trace, resume and shade kernels of the PT path and the extend, connect and
+                                      * reduce kernels of the BDPT path walk their queues with a stride; k_bdpt_vertex keeps
+                                      * its one-chunk-per-workgroup grid, whose workgroups return at once on an empty
+                                      * queue), so an iteration that finds its queue empty costs a few microseconds per
+                                      * launch: config 3 with the default max_delta of 64, of which it needs 4, renders
+                                      * in the same 131 ms either way.  What it costs is a fixed ~200 (PT) / ~260 (BDPT)
                                       * launches per pass, i.e. about a millisecond on a render of a few milliseconds --
                                       * hence opt-in; the default looks at a 4-byte counter every other tail iteration.
                                       * Same image */

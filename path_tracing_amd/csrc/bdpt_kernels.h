@@ -63,16 +63,17 @@ void launch_bdpt_light_trace(hipStream_t s, const BdptSceneDev &sc, LightVertexD
                              int spl, uint64_t seed, int max_delta);
 void launch_bdpt_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb, BdptPathBuf bp, uint32_t *qcount,
                           int samples_this_pass, uint32_t first_sample, uint64_t seed);
+// max_groups != 0 caps the grid of extend / connect / reduce (they walk their queues with a stride)
 void launch_bdpt_extend(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
-                        uint32_t max_items);
+                        uint32_t max_items, uint32_t max_groups = 0);
 void launch_bdpt_light_ctx(hipStream_t s, const LightVertexDev *lv, LightVertexCtx *ctx, int n_lv, int light_depth);
 void launch_bdpt_vertex(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptPathBuf bp, const uint32_t *queue,
                         const uint32_t *qcount, uint32_t max_items, uint32_t *next_queue, uint32_t *next_count,
                         uint32_t *cqueue, uint32_t *ccount, int eye_depth, int max_delta, uint32_t slots, const float eye[3]);
 void launch_bdpt_connect(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lv,
                          const LightVertexCtx *lctx, int n_lv, int light_depth, const uint32_t *cqueue, const uint32_t *ccount,
-                         uint32_t max_items, uint32_t slots);
+                         uint32_t max_items, uint32_t slots, uint32_t max_groups = 0);
 void launch_bdpt_reduce(hipStream_t s, PathBuf pb, BdptPathBuf bp, int n_lv, const uint32_t *cqueue, const uint32_t *ccount,
-                        uint32_t max_items);
+                        uint32_t max_items, uint32_t max_groups = 0);
 
 } // namespace hpt

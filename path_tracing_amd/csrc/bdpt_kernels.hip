@@ -750,12 +750,15 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
         __syncthreads();
         // ---- phase 2: a full workgroup of survivors, taken from the top of the list ----
         uint32_t n = s_n;
+        // every wave has its snapshot of the count before any wave can push again: without this barrier a wave that
+        // runs ahead into the next trip's lds_push could change s_n under a slower wave's read, and the waves of one
+        // workgroup would then disagree about taking the branch below (which holds a barrier)
+        __syncthreads();
         if(n >= (uint32_t) kBlock){
             uint32_t e = n - (uint32_t) kBlock + threadIdx.x;
             evaluate(s_pair_path[e], (int) s_pair_j[e]);
-            __syncthreads();
-            if(threadIdx.x == 0) s_n = n - (uint32_t) kBlock;
-            __syncthreads();
+            if(threadIdx.x == 0) s_n = n - (uint32_t) kBlock;       // nobody reads s_n or pushes before the barrier below
+            __syncthreads();                                        // the list entries above n - kBlock have been read
         }
     }
     uint32_t n = s_n;
@@ -827,9 +830,13 @@ void launch_bdpt_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam,
     uint32_t total = (uint32_t) tl.n_local * (uint32_t) samples_this_pass;
     hipLaunchKernelGGL(k_bdpt_generate, dim3(grid_for(total)), dim3(kBlock), 0, s, tl, cam, pb, bp, qcount, total, first_sample, seed);
 }
+// max_groups != 0 caps the grid (the blind tail iterations of HPT_FLAG_NO_HOST_WAIT): extend, connect and reduce walk
+// their queues with a stride, so a small grid is only slower when the queue is long -- which it is not there
+static uint32_t capped(uint32_t g, uint32_t max_groups){ return max_groups != 0u && g > max_groups ? max_groups : g; }
+
 void launch_bdpt_extend(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
-                        uint32_t max_items){
-    hipLaunchKernelGGL(k_bdpt_extend, dim3(grid_for(max_items)), dim3(kBlock), 0, s, sc, pb, queue, qcount);
+                        uint32_t max_items, uint32_t max_groups){
+    hipLaunchKernelGGL(k_bdpt_extend, dim3(capped(grid_for(max_items), max_groups)), dim3(kBlock), 0, s, sc, pb, queue, qcount);
 }
 void launch_bdpt_vertex(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptPathBuf bp, const uint32_t *queue,
                         const uint32_t *qcount, uint32_t max_items, uint32_t *next_queue, uint32_t *next_count,
@@ -847,18 +854,18 @@ void launch_bdpt_light_ctx(hipStream_t s, const LightVertexDev *lv, LightVertexC
 }
 void launch_bdpt_connect(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lv,
                          const LightVertexCtx *lctx, int n_lv, int light_depth, const uint32_t *cqueue, const uint32_t *ccount,
-                         uint32_t max_items, uint32_t slots){
+                         uint32_t max_items, uint32_t slots, uint32_t max_groups){
     unsigned long long waves = (unsigned long long) max_items * (((unsigned) n_lv + 63u) / 64u);
     unsigned long long g = (waves + (kBlock / 64) - 1) / (kBlock / 64);
     if(g < 1ull) g = 1ull;
     if(g > 4096ull) g = 4096ull;            // several trips per workgroup: the survivor list fills up across them
     const size_t stack_bytes = (size_t) (sc.stack_levels > 0 ? sc.stack_levels : kStackDepth) * kBlock * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_bdpt_connect, dim3((uint32_t) g), dim3(kBlock), stack_bytes, s, sc, pb, bp, lv, lctx, n_lv, light_depth, cqueue, ccount,
+    hipLaunchKernelGGL(k_bdpt_connect, dim3(capped((uint32_t) g, max_groups)), dim3(kBlock), stack_bytes, s, sc, pb, bp, lv, lctx, n_lv, light_depth, cqueue, ccount,
                        slots);
 }
 void launch_bdpt_reduce(hipStream_t s, PathBuf pb, BdptPathBuf bp, int n_lv, const uint32_t *cqueue, const uint32_t *ccount,
-                        uint32_t max_items){
-    hipLaunchKernelGGL(k_bdpt_reduce, dim3(grid_for(max_items)), dim3(kBlock), 0, s, pb, bp, n_lv, cqueue, ccount);
+                        uint32_t max_items, uint32_t max_groups){
+    hipLaunchKernelGGL(k_bdpt_reduce, dim3(capped(grid_for(max_items), max_groups)), dim3(kBlock), 0, s, pb, bp, n_lv, cqueue, ccount);
 }
 
 } // namespace hpt

@@ -59,6 +59,8 @@ struct DevBuf {              // device allocation released on every return path
 
 struct TimedLaunch { hipEvent_t a, b; int cls; };
 constexpr int kSplitHold = 15;
+// device memory per path slot of one pipeline (ensure_pass): path state 80 B, pending shadow ray 48 B, five queues of 4 B
+constexpr double kBytesPerPathSlot = 148.0;
 
 static_assert(sizeof(hpt_stats) == 248 && sizeof(hpt_params) == 40, "ABI records: keep path_tracing_amd/__init__.py and tests/test_boundary.py in step");
 
@@ -276,7 +278,23 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     bool dual = !(flags & HPT_FLAG_SINGLE_PIPELINE) && !count && !legacy;
     int spass = P.samples_per_pass;
     if(spass <= 0){
-        const long long target = 128ll << 20;
+        long long target = 128ll << 20;
+        // ... on a device that has the memory for it: when the workspace would have to grow, the pass is sized so that
+        // both pipelines' state fits in 70 % of what is free now plus what the scene already holds (a smaller device,
+        // or several scenes on one device, get smaller passes instead of HPT_ERR_NOMEM; the image does not depend on it)
+        const size_t have = s->pass[0].cap_paths + s->pass[1].cap_paths;
+        if((size_t) std::min<long long>(target, (long long) tl.n_local * spp) > s->pass[0].cap_paths){
+            size_t free_b = 0, total_b = 0;
+            if(hipMemGetInfo(&free_b, &total_b) == hipSuccess){
+                const double usable = 0.7 * ((double) free_b + (double) have * kBytesPerPathSlot);
+                const long long fit = (long long) (usable / (kBytesPerPathSlot * (dual ? 2.0 : 1.0)));
+                if(fit < target){
+                    target = std::max<long long>(fit, tl.n_local);
+                    // a workspace sized this way earlier is kept (no reallocation for a few per cent more)
+                    if((long long) s->pass[0].cap_paths >= target * 3 / 4) target = (long long) s->pass[0].cap_paths;
+                }
+            } else (void) hipGetLastError();
+        }
         spass = (int) std::max<long long>(1, target / tl.n_local);
         spass = std::min(spass, spp);
         if(dual && spass == spp && spp >= 2 && (long long) tl.n_local * spp >= (1ll << 20)) spass = (spp + 1) / 2;
@@ -394,7 +412,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                            q.pending_shadow >= 0 ? &q.scnt[q.pending_shadow] : nullptr, q.slots, s->stack_levels, kflags, tuning, wc, &split, primary, cap); }
             if(split.budget > 0){
                 LaunchTimer t(s, q.st, timek, 4);
-                launch_trace_resume(q.st, s->sd, q.pb, q.sb, true, q.pending_shadow >= 0, q.slots, s->stack_levels, wc, split, primary);
+                launch_trace_resume(q.st, s->sd, q.pb, q.sb, true, q.pending_shadow >= 0, q.slots, s->stack_levels, wc, split, primary, cap);
             }
             q.pending_shadow = -1;
         }
@@ -438,7 +456,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                            s->stack_levels, kflags, tuning, wc, &split, nullptr, blind_groups); }
             if(split.budget > 0){
                 LaunchTimer t(s, q.st, timek, 4);
-                launch_trace_resume(q.st, s->sd, q.pb, q.sb, false, true, q.slots, s->stack_levels, wc, split);
+                launch_trace_resume(q.st, s->sd, q.pb, q.sb, false, true, q.slots, s->stack_levels, wc, split, nullptr, blind_groups);
             }
         }
         return HPT_OK;
@@ -684,16 +702,19 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
                     if(*s->pass[0].h_count == 0u) break;
                 }
                 const uint32_t *eq = it == 0 ? nullptr : s->pass[0].queue[cur];
+                // unseen tail iterations: small fixed grids for the three kernels that walk their queue with a stride
+                // (k_bdpt_vertex keeps its grid: one chunk per workgroup, an empty one returns at once)
+                const uint32_t cap = (it >= eye_depth && (P.flags & HPT_FLAG_NO_HOST_WAIT)) ? (uint32_t) std::max(s->num_cus, 1) * 8u : 0u;
                 { LaunchTimer t(s, stream, timek, 0);
-                  launch_bdpt_extend(stream, s->bd, s->pass[0].pb, eq, &qcnt[ci], nslots); }
+                  launch_bdpt_extend(stream, s->bd, s->pass[0].pb, eq, &qcnt[ci], nslots, cap); }
                 { LaunchTimer t(s, stream, timek, 1);
                   launch_bdpt_vertex(stream, s->bd, s->pass[0].pb, s->bp, eq, &qcnt[ci], nslots, s->pass[0].queue[cur ^ 1], &qcnt[ci + 1],
                                      s->cqueue, &ccnt[ci], eye_depth, P.max_delta, (uint32_t) slots, cam.eye); }
                 { LaunchTimer t(s, stream, timek, 2);
                   launch_bdpt_connect(stream, s->bd, s->pass[0].pb, s->bp, s->d_lv, s->d_lctx, n_lv, light_depth, s->cqueue, &ccnt[ci], nslots,
-                                      (uint32_t) slots); }
+                                      (uint32_t) slots, cap); }
                 { LaunchTimer t(s, stream, timek, 3);
-                  launch_bdpt_reduce(stream, s->pass[0].pb, s->bp, n_lv, s->cqueue, &ccnt[ci], nslots); }
+                  launch_bdpt_reduce(stream, s->pass[0].pb, s->bp, n_lv, s->cqueue, &ccnt[ci], nslots, cap); }
                 cur ^= 1;
             }
             { LaunchTimer t(s, stream, timek, 3);

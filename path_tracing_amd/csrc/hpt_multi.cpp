@@ -145,11 +145,18 @@ int exchange_and_assemble(hpt_multi *m, size_t n_local, int W, int H, const hpt_
     if(m->exchange == 0){
         Rccl &R = rccl();
         NCCL_TRY(R.GroupStart());
-        for(int d = 0; d < m->n; ++d){
-            MHIP_TRY(hipSetDevice(m->dev[d]));
-            NCCL_TRY(R.Gather(m->d_local[d], d == 0 ? m->d_gathered : nullptr, count, ncclFloat, 0, m->comm[d], m->stream[d]));
+        // the group is closed on every path: the first failure inside it is kept and returned after GroupEnd (an open
+        // group would swallow every later RCCL call of this thread, ncclCommDestroy in hpt_multi_destroy included)
+        std::string first_error;
+        for(int d = 0; d < m->n && first_error.empty(); ++d){
+            hipError_t e = hipSetDevice(m->dev[d]);
+            if(e != hipSuccess){ first_error = std::string("hipSetDevice: ") + hipGetErrorString(e); break; }
+            ncclResult_t r = R.Gather(m->d_local[d], d == 0 ? m->d_gathered : nullptr, count, ncclFloat, 0, m->comm[d], m->stream[d]);
+            if(r != ncclSuccess) first_error = std::string("ncclGather (rank ") + std::to_string(d) + "): " + R.GetErrorString(r);
         }
-        NCCL_TRY(R.GroupEnd());
+        ncclResult_t ge = R.GroupEnd();
+        if(!first_error.empty()){ (void) hipSetDevice(m->dev[0]); return fail_with(HPT_ERR_DEVICE, first_error); }
+        if(ge != ncclSuccess) return fail_with(HPT_ERR_DEVICE, std::string("ncclGroupEnd: ") + R.GetErrorString(ge));
         MHIP_TRY(hipSetDevice(m->dev[0]));
     } else {
         for(int d = 0; d < m->n; ++d){

@@ -89,7 +89,7 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
                   const TraceSplit *split = nullptr, const PrimaryGen *primary = nullptr, uint32_t max_groups = 0);
 void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
                          uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split,
-                         const PrimaryGen *primary = nullptr);
+                         const PrimaryGen *primary = nullptr, uint32_t max_groups = 0);
 // fills frames[4 * num_tris] from tris (once per scene)
 void launch_tri_frames(hipStream_t s, const float4 *tris, int num_tris, float4 *frames);
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass);

@@ -1243,7 +1243,8 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
 // second launch of a split trace step: the rays launch_trace set aside.  Their number is only known on
 // the device, so a fixed grid walks the chunks.
 void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
-                         uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split, const PrimaryGen *primary){
+                         uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split, const PrimaryGen *primary,
+                         uint32_t max_groups){
     if(!extend && !shadow) return;
     if(stack_levels < 1) stack_levels = 1;
     if(stack_levels > kStackDepth) stack_levels = kStackDepth;
@@ -1254,6 +1255,7 @@ void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBu
     uint32_t per = (max_items + kBlock - 1) / kBlock;
     uint64_t g = (uint64_t) per * ((extend ? 1u : 0u) + (shadow ? 1u : 0u));
     uint32_t g2 = g < 8192u ? (uint32_t) (g < 1u ? 1u : g) : 8192u;
+    if(max_groups != 0u && g2 > max_groups) g2 = max_groups;          // blind tail iterations (HPT_FLAG_NO_HOST_WAIT)
     LongQueues none{};
     PrimaryGen no_primary{};
     if(primary && extend)

@@ -243,7 +243,9 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
 
     auto t0 = std::chrono::steady_clock::now();
     Builder B;
-    if(const char *e = getenv("HPT_MAX_LEAF")){ int v = atoi(e); if(v >= 1 && v <= 8) B.max_leaf = v; }   // tuning experiments
+#ifdef HPT_DEV_TUNING      // development builds only (`make variant EXTRA=-DHPT_DEV_TUNING`, scripts/sweep_leaf.py): the product reads no environment here
+    if(const char *e = getenv("HPT_MAX_LEAF")){ int v = atoi(e); if(v >= 1 && v <= 8) B.max_leaf = v; }
+#endif
     B.prims.resize(nt);
     Box scene_box; scene_box.reset();
     for(int i = 0; i < nt; ++i){

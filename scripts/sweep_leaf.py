@@ -1,4 +1,4 @@
-"""A/B of the BVH leaf size (HPT_MAX_LEAF, read when a scene is built) x node-step budget of the first trace launch:
+"""A/B of the BVH leaf size (HPT_MAX_LEAF, read when a scene is built by a development build: `make variant VARIANT=dev EXTRA=-DHPT_DEV_TUNING`, HPT_LIBRARY=.../libhpt_dev.so) x node-step budget of the first trace launch:
 ms per pass, single pipeline.  AB_SCENE: sphere (config 3 / 5 shape) | random (incoherent small triangles) | input"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
