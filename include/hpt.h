@@ -252,6 +252,29 @@ int hpt_tonemap_host(const float *linear_rgb, unsigned char *rgb8, int64_t num_p
 void hpt_tonemap_table(float thresholds_out[256]);
 void hpt_tonemap_reference(const float *linear_rgb, unsigned char *rgb8, int64_t num_pixels, int bgr);
 
+/* ---- the acceleration structure, exported (tests) -------------------------------------
+ * The reference has no acceleration structure (include/geometric.cuh:293-388 scan every primitive); the tree the
+ * kernels walk is this library's own, and the work counts the bench's roofline is built from (hpt_stats.boxes_*,
+ * tris_*) are counts of walking it.  These two calls hand the tree out so that an independent walker -- the oracle's
+ * host traversal, oracle/pt_oracle.cpp -- can reproduce those counts ray by ray.
+ *   qnodes_out  num_nodes records of 32 B: child boxes lmin, lmax, rmin, rmax as 3 x uint16 grid coordinates each
+ *               (coordinate = qorigin + q * qscale), then the two uint32 child codes: bit 31 set = leaf,
+ *               (code & 0x7FFFFFFF) >> 3 = first triangle slot, (code & 7) + 1 = triangle count; 0xFFFFFFFF = no
+ *               child; otherwise the index of an inner node.  Node 0 is the root.
+ *   tris_out    num_tris records of 48 B in leaf order: v0 | scan ordinal, v1 - v0 | material, v2 - v0 | flags
+ * Either output may be NULL (sizes only); the caps are in bytes and must cover what is written.
+ * hpt_bvh_export_host builds on the host only (no device needed) exactly what hpt_scene_create would upload;
+ * hpt_scene_export_bvh copies back what the scene's device actually holds. */
+typedef struct hpt_bvh_info {
+    int32_t num_nodes, num_tris, bvh_depth, num_rounds;   /* num_rounds = spheres + light balls: the first triangle ordinal */
+    float qorigin[3], qscale[3];
+} hpt_bvh_info;
+int hpt_bvh_export_host(const void *lights, int num_lights, const void *spheres, int num_spheres,
+                        const void *triangles, int num_triangles, hpt_bvh_info *info,
+                        void *qnodes_out, size_t qnodes_cap, void *tris_out, size_t tris_cap);
+int hpt_scene_export_bvh(const hpt_scene *scene, hpt_bvh_info *info,
+                         void *qnodes_out, size_t qnodes_cap, void *tris_out, size_t tris_cap);
+
 /* Ray-level probes of the intersection kernels (tests): n rays, origins/directions as
  * packed float3.  prim is the reference scan ordinal (spheres, then light balls, then
  * triangles in input order), -1 on a miss; t is 1e20f on a miss. */

@@ -24,10 +24,17 @@ class PtOpts(C.Structure):
 
 class PtStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "bounces",
-                                          "delta_bounces", "tri_tests", "sphere_tests")]
+                                          "delta_bounces", "tri_tests", "sphere_tests",
+                                          "boxes_closest", "tris_closest", "boxes_shadow", "tris_shadow")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class Bvh(C.Structure):
+    """The tree libhpt.so exports (include/hpt.h, hpt_bvh_info): handed to pt_render(bvh=...) as a dict."""
+    _fields_ = [("qnodes", C.c_void_p), ("num_nodes", C.c_int), ("tris", C.c_void_p), ("num_tris", C.c_int),
+                ("num_rounds", C.c_int), ("qorigin", C.c_float * 3), ("qscale", C.c_float * 3)]
 
 
 def build(force: bool = False) -> str:
@@ -54,9 +61,12 @@ def _p(a):
 
 
 def pt_render(lights, spheres, tris, camera, W, H, max_depth, spp, *, seed=1, rng_mode=0, trig_mode=0,
-              sample_offset=0, window=None, threads=0, glass_shadow_opaque=0, max_delta=64, output_sum=False, ball_draw_reversed=False, russian_roulette=False):
+              sample_offset=0, window=None, threads=0, glass_shadow_opaque=0, max_delta=64, output_sum=False, ball_draw_reversed=False, russian_roulette=False,
+              bvh=None):
     """Unidirectional PT + NEE (restates src/pt_cu.cu:20-250).  Returns (image[H,W,3] f32, stats dict).
-    Pixels outside `window` = (x0, y0, x1, y1) stay zero."""
+    Pixels outside `window` = (x0, y0, x1, y1) stay zero.  bvh: the dict path_tracing_amd.export_bvh_host /
+    Scene.export_bvh return -- triangles are then found by walking that tree on the host (same image as the scan) and
+    stats carry boxes_* / tris_*: the independent count behind the bench's algorithmic bytes."""
     img = np.zeros((H, W, 3), np.float32)
     o = PtOpts()
     o.seed, o.rng_mode, o.trig_mode, o.sample_offset = int(seed), rng_mode, trig_mode, sample_offset
@@ -69,9 +79,20 @@ def pt_render(lights, spheres, tris, camera, W, H, max_depth, spp, *, seed=1, rn
     lights = np.ascontiguousarray(lights)
     spheres = np.ascontiguousarray(spheres)
     tris = np.ascontiguousarray(tris)
-    rc = lib().oracle_pt_render(_p(lights), len(lights), _p(spheres), len(spheres), _p(tris), len(tris),
-                                cam.ctypes.data_as(C.c_void_p), img.ctypes.data_as(C.c_void_p),
-                                W, H, max_depth, spp, C.byref(o), C.byref(st))
+    b = None
+    if bvh is not None:
+        qn = np.ascontiguousarray(bvh["qnodes"], np.uint32)
+        tw = np.ascontiguousarray(bvh["tris"], np.uint32)
+        b = Bvh()
+        b.qnodes, b.num_nodes, b.tris, b.num_tris = qn.ctypes.data, int(bvh["num_nodes"]), tw.ctypes.data, int(bvh["num_tris"])
+        b.num_rounds = int(bvh["num_rounds"])
+        b.qorigin = (C.c_float * 3)(*[float(v) for v in bvh["qorigin"]])
+        b.qscale = (C.c_float * 3)(*[float(v) for v in bvh["qscale"]])
+    fn = lib().oracle_pt_render_bvh
+    fn.restype = C.c_int
+    rc = fn(_p(lights), len(lights), _p(spheres), len(spheres), _p(tris), len(tris),
+            cam.ctypes.data_as(C.c_void_p), img.ctypes.data_as(C.c_void_p),
+            W, H, max_depth, spp, C.byref(o), C.byref(st), C.byref(b) if b is not None else None)
     if rc != 0:
         raise RuntimeError("oracle_pt_render failed rc=%d" % rc)
     return img, st.as_dict()

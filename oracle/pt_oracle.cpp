@@ -43,6 +43,18 @@ struct OraclePtOpts {
 
 struct OraclePtStats {
     uint64_t samples, closest_rays, shadow_rays, bounces, delta_bounces, tri_tests, sphere_tests;
+    // host walk of the library's exported tree (oracle_pt_render_bvh only): child boxes slab-tested (2 per inner-node
+    // visit) and triangle tests, by closest-hit and by shadow rays -- what hpt_stats.boxes_* / tris_* must equal
+    uint64_t boxes_closest, tris_closest, boxes_shadow, tris_shadow;
+};
+
+// The tree libhpt.so built for the scene (include/hpt.h, hpt_bvh_info / hpt_bvh_export_host): the reference has no
+// acceleration structure, so this is not restated from it -- the walk below is the independent count SURVEY 8(d) asks for.
+struct OracleBvh {
+    const uint32_t *qnodes; int num_nodes;     // 8 words per node
+    const uint32_t *tris; int num_tris;        // 12 words per triangle, leaf order; word 3 = scan ordinal
+    int num_rounds;                            // spheres + light balls = ordinal of input triangle 0
+    float qorigin[3], qscale[3];
 };
 
 } // extern "C"
@@ -62,7 +74,102 @@ struct Scene {
     const RSphere *spheres; int ns;
     const RTriangle *tris; int nt;
     std::vector<float> cos_cutoff;     // cosf(light.cutoff), hoisted (pt_cu.cu:73,79,168)
+    const OracleBvh *bvh = nullptr;    // non-null: triangles are found by walking the library's tree instead of the scan
 };
+
+// ---- host walk of the exported tree ----------------------------------------------------------
+// Visits what one ray of the device's plain traversal visits, in its order (path_tracing_amd/csrc/pt_kernels.hip,
+// trace_chunk without a budget): a node step slab-tests both children's quantised boxes, descends into the nearer hit
+// child and stacks the other; a leaf tests all of its triangles; the walk ends on an empty stack.  The primitive test is
+// the oracle's own intersect_triangle on the INPUT triangle the leaf slot's ordinal names, so the hit found is what the
+// brute-force scan finds as long as the boxes are conservative -- and the scan's strict '<' tie rule is kept by
+// preferring the lower ordinal at equal t.
+constexpr uint32_t kLeaf = 0x80000000u, kNoChild = 0xFFFFFFFFu, kDone = 0xFFFFFFFEu;
+
+struct WalkRay {
+    float ix, iy, iz, ox, oy, oz;
+    WalkRay(const OracleBvh &b, V3 ro, V3 rd){
+        float dx = fabsf(rd.x) > 1e-20f ? rd.x : copysignf(1e-20f, rd.x);
+        float dy = fabsf(rd.y) > 1e-20f ? rd.y : copysignf(1e-20f, rd.y);
+        float dz = fabsf(rd.z) > 1e-20f ? rd.z : copysignf(1e-20f, rd.z);
+        ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+        ox = (b.qorigin[0] - ro.x) * ix; oy = (b.qorigin[1] - ro.y) * iy; oz = (b.qorigin[2] - ro.z) * iz;
+        ix *= b.qscale[0]; iy *= b.qscale[1]; iz *= b.qscale[2];
+    }
+};
+
+// one inner-node step: returns the next code and updates the stack
+static inline uint32_t node_step(const OracleBvh &b, const WalkRay &r, uint32_t cur, float limit, uint32_t *stk, int &sp){
+    const uint32_t *w = b.qnodes + (size_t) cur * 8;
+    float a0 = fmaf((float) (w[0] & 0xFFFFu), r.ix, r.ox), a1 = fmaf((float) (w[1] >> 16), r.ix, r.ox);
+    float b0 = fmaf((float) (w[0] >> 16), r.iy, r.oy), b1 = fmaf((float) (w[2] & 0xFFFFu), r.iy, r.oy);
+    float c0 = fmaf((float) (w[1] & 0xFFFFu), r.iz, r.oz), c1 = fmaf((float) (w[2] >> 16), r.iz, r.oz);
+    float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+    float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
+    a0 = fmaf((float) (w[3] & 0xFFFFu), r.ix, r.ox); a1 = fmaf((float) (w[4] >> 16), r.ix, r.ox);
+    b0 = fmaf((float) (w[3] >> 16), r.iy, r.oy); b1 = fmaf((float) (w[5] & 0xFFFFu), r.iy, r.oy);
+    c0 = fmaf((float) (w[4] & 0xFFFFu), r.iz, r.oz); c1 = fmaf((float) (w[5] >> 16), r.iz, r.oz);
+    float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
+    float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
+    uint32_t lc = w[6], rc = w[7];
+    bool hl = (ln <= lf * 1.000002f) && (lc != kNoChild);
+    bool hr = (rn <= rf * 1.000002f) && (rc != kNoChild);
+    bool any = hl || hr, both = hl && hr;
+    bool left_first = hl && (!hr || ln <= rn);
+    if(both){ stk[sp++] = left_first ? rc : lc; return left_first ? lc : rc; }
+    if(any) return left_first ? lc : rc;
+    if(sp > 0) return stk[--sp];
+    return kDone;
+}
+
+// closest triangle hit below best_t (ties: lower ordinal); returns the INPUT index of the triangle or -1
+int walk_closest(const Scene &sc, V3 ro, V3 rd, float &best_t, uint32_t best_ord, uint64_t &boxes, uint64_t &tris){
+    const OracleBvh &b = *sc.bvh;
+    WalkRay r(b, ro, rd);
+    uint32_t stk[128]; int sp = 0;
+    uint32_t cur = 0u;
+    int found = -1;
+    for(;;){
+        while(!(cur & kLeaf)){ boxes += 2; cur = node_step(b, r, cur, best_t, stk, sp); }
+        if(cur == kDone) break;
+        uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = (cur & 7u) + 1u;
+        for(uint32_t k = 0; k < cnt; ++k){
+            tris += 1;
+            uint32_t ord = b.tris[(size_t) (first + k) * 12 + 3];
+            const RTriangle &tr = sc.tris[ord - (uint32_t) b.num_rounds];
+            float t;
+            if(intersect_triangle(ro, rd, tr.v0, tr.v1, tr.v2, t, 1e20f) && (t < best_t || (t == best_t && ord < best_ord))){
+                best_t = t; best_ord = ord; found = (int) (ord - (uint32_t) b.num_rounds);
+            }
+        }
+        if(sp > 0) cur = stk[--sp]; else break;
+    }
+    return found;
+}
+
+// true when an opaque triangle blocks (1e-3, max_d)
+bool walk_any(const Scene &sc, V3 p1, V3 dir, float max_d, bool glass_opaque, uint64_t &boxes, uint64_t &tris){
+    const OracleBvh &b = *sc.bvh;
+    WalkRay r(b, p1, dir);
+    uint32_t stk[128]; int sp = 0;
+    uint32_t cur = 0u;
+    for(;;){
+        while(!(cur & kLeaf)){ boxes += 2; cur = node_step(b, r, cur, max_d, stk, sp); }
+        if(cur == kDone) break;
+        uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = (cur & 7u) + 1u;
+        bool blocked = false;
+        for(uint32_t k = 0; k < cnt; ++k){            // the device tests every triangle of the leaf before it looks
+            tris += 1;
+            uint32_t ord = b.tris[(size_t) (first + k) * 12 + 3];
+            const RTriangle &tr = sc.tris[ord - (uint32_t) b.num_rounds];
+            float t;
+            if(intersect_triangle(p1, dir, tr.v0, tr.v1, tr.v2, t, max_d) && t > 1e-3f && (glass_opaque || tr.mtl.eta <= 0.0f)) blocked = true;
+        }
+        if(blocked) return true;
+        if(sp > 0) cur = stk[--sp]; else break;
+    }
+    return false;
+}
 
 // geometric.cuh:327-388 -- spheres, then light balls, then triangles; strict '<'
 Hit closest_hit(const Scene &sc, V3 ro, V3 rd, OraclePtStats &st){
@@ -71,7 +178,7 @@ Hit closest_hit(const Scene &sc, V3 ro, V3 rd, OraclePtStats &st){
     best.pos = v3(0, 0, 0); best.normal = v3(0, 0, 0);
     float t; const float max_dist = 1e20f;
     st.sphere_tests += (uint64_t) (sc.ns + sc.nl);
-    st.tri_tests += (uint64_t) sc.nt;
+    if(!sc.bvh) st.tri_tests += (uint64_t) sc.nt;
     for(int i = 0; i < sc.ns; ++i){
         const RSphere &s = sc.spheres[i];
         if(intersect_sphere(ro, rd, s.center, s.r, t, max_dist) && t < best.t){
@@ -92,6 +199,20 @@ Hit closest_hit(const Scene &sc, V3 ro, V3 rd, OraclePtStats &st){
             best.is_light = true; best.prim = sc.ns + i;
             if(dot(best.normal, rd) > 0.0f) best.normal = best.normal * -1.0f;
         }
+    }
+    if(sc.bvh){
+        // same answer through the library's tree (a sphere or light ball at equal t keeps the hit: lower ordinal)
+        float bt = best.t;
+        int i = walk_closest(sc, ro, rd, bt, best.hit ? (uint32_t) best.prim : 0xFFFFFFFFu, st.boxes_closest, st.tris_closest);
+        if(i >= 0){
+            const RTriangle &tr = sc.tris[i];
+            best.hit = true; best.t = bt; best.mtl = tr.mtl;
+            best.pos = ro + rd * bt;
+            best.normal = normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0));
+            best.is_light = false; best.prim = sc.ns + sc.nl + i;
+            if(dot(best.normal, rd) > 0.0f) best.normal = best.normal * -1.0f;
+        }
+        return best;
     }
     for(int i = 0; i < sc.nt; ++i){
         const RTriangle &tr = sc.tris[i];
@@ -114,6 +235,17 @@ bool visible(const Scene &sc, V3 p1, V3 p2, bool glass_opaque, OraclePtStats &st
     float max_d = dist - 1e-3f;
     const float min_d = 1e-3f;
     float t;
+    if(sc.bvh){
+        // the device's order: spheres first (a blocked ray never enters the tree), then the any-hit walk
+        st.sphere_tests += (uint64_t) sc.ns;
+        bool blocked = false;
+        for(int i = 0; i < sc.ns; ++i){
+            const RSphere &s = sc.spheres[i];
+            if(intersect_sphere(p1, dir, s.center, s.r, t, max_d) && t > min_d && (glass_opaque || s.mtl.eta <= 0.0f)) blocked = true;
+        }
+        if(blocked) return false;
+        return !walk_any(sc, p1, dir, max_d, glass_opaque, st.boxes_shadow, st.tris_shadow);
+    }
     st.tri_tests += (uint64_t) sc.nt;
     st.sphere_tests += (uint64_t) sc.ns;
     for(int i = 0; i < sc.nt; ++i){
@@ -289,11 +421,24 @@ extern "C" {
 
 // Renders the window [x0,x1)x[y0,y1) of a W x H image; pixels outside are left untouched.
 // Arguments mirror pt_render_wrapper (reference: include/pt_cu.cuh:6-13).
+int oracle_pt_render_bvh(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                         const void *camera, float *image, int W, int H, int max_depth, int spp,
+                         const OraclePtOpts *opts, OraclePtStats *stats_out, const OracleBvh *bvh);
+
 int oracle_pt_render(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
                      const void *camera, float *image, int W, int H, int max_depth, int spp,
                      const OraclePtOpts *opts, OraclePtStats *stats_out){
+    return oracle_pt_render_bvh(lights, nl, spheres, ns, tris, nt, camera, image, W, H, max_depth, spp, opts, stats_out, nullptr);
+}
+
+// bvh != null: the same estimator with the triangles found through the library's exported tree, counting the walk
+int oracle_pt_render_bvh(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt,
+                         const void *camera, float *image, int W, int H, int max_depth, int spp,
+                         const OraclePtOpts *opts, OraclePtStats *stats_out, const OracleBvh *bvh){
     if(!camera || !image || !opts || W <= 0 || H <= 0 || spp <= 0) return 1;
+    if(bvh && (bvh->num_tris != nt || bvh->num_rounds != ns + nl || bvh->num_nodes < 1 || !bvh->qnodes || (nt > 0 && !bvh->tris))) return 2;
     Scene sc;
+    sc.bvh = bvh;
     sc.lights = (const RLight *) lights; sc.nl = nl;
     sc.spheres = (const RSphere *) spheres; sc.ns = ns;
     sc.tris = (const RTriangle *) tris; sc.nt = nt;
@@ -334,6 +479,8 @@ int oracle_pt_render(const void *lights, int nl, const void *spheres, int ns, co
             t.samples += s.samples; t.closest_rays += s.closest_rays; t.shadow_rays += s.shadow_rays;
             t.bounces += s.bounces; t.delta_bounces += s.delta_bounces; t.tri_tests += s.tri_tests;
             t.sphere_tests += s.sphere_tests;
+            t.boxes_closest += s.boxes_closest; t.tris_closest += s.tris_closest;
+            t.boxes_shadow += s.boxes_shadow; t.tris_shadow += s.tris_shadow;
         }
         *stats_out = t;
     }

@@ -61,6 +61,15 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class BvhInfo(C.Structure):
+    _fields_ = [("num_nodes", C.c_int32), ("num_tris", C.c_int32), ("bvh_depth", C.c_int32), ("num_rounds", C.c_int32),
+                ("qorigin", C.c_float * 3), ("qscale", C.c_float * 3)]
+
+
+# exported tree (include/hpt.h, hpt_bvh_info): 32-B quantised nodes as 8 uint32 words, 48-B triangles as 12 words
+QNODE_WORDS = 8
+TRI_WORDS = 12
+
 _lib = None
 
 
@@ -102,7 +111,7 @@ def load_library() -> C.CDLL:
                      "hpt_pt_render_wrapper", "hpt_get_stats", "hpt_trace_closest", "hpt_trace_visibility",
                      "hpt_device_count", "hpt_multi_create", "hpt_multi_num_devices", "hpt_multi_set_groups",
                      "hpt_multi_render_pt", "hpt_multi_render_bdpt", "hpt_multi_get_timing", "hpt_wrapper_set_devices",
-                     "hpt_probe_functions", "hpt_tonemap", "hpt_tonemap_host"):
+                     "hpt_probe_functions", "hpt_tonemap", "hpt_tonemap_host", "hpt_bvh_export_host", "hpt_scene_export_bvh"):
             getattr(lib, name).restype = C.c_int
         lib.hpt_scene_destroy.restype = None
         lib.hpt_wrapper_cache_clear.restype = None
@@ -212,6 +221,11 @@ class Scene:
         _check(self._lib.hpt_get_stats(self._h, C.byref(st)))
         return st.as_dict()
 
+    def export_bvh(self) -> dict:
+        """The tree this scene's device holds (include/hpt.h, hpt_scene_export_bvh): dict(info, qnodes [n, 8] uint32,
+        tris [m, 12] uint32 words of the 48-B leaf-order records)."""
+        return _export_bvh(lambda info, qn, qcap, tr, tcap: self._lib.hpt_scene_export_bvh(self._h, info, qn, qcap, tr, tcap))
+
     # -- ray probes (tests) ---------------------------------------------------------------
     def trace_closest(self, origins, dirs, brute_force=False):
         o = np.ascontiguousarray(origins, np.float32)
@@ -291,6 +305,27 @@ class MultiScene:
         g = C.c_double(); t = C.c_double()
         _check(self._lib.hpt_multi_get_timing(self._h, per, C.byref(g), C.byref(t)))
         return {"render_ms_per_device": list(per), "gather_ms": g.value, "total_ms": t.value}
+
+
+def _export_bvh(call) -> dict:
+    info = BvhInfo()
+    _check(call(C.byref(info), None, C.c_size_t(0), None, C.c_size_t(0)))
+    qn = np.zeros((max(info.num_nodes, 1), QNODE_WORDS), np.uint32)
+    tr = np.zeros((max(info.num_tris, 1), TRI_WORDS), np.uint32)
+    _check(call(C.byref(info), _vp(qn), C.c_size_t(qn.nbytes), _vp(tr), C.c_size_t(tr.nbytes)))
+    return {"num_nodes": info.num_nodes, "num_tris": info.num_tris, "bvh_depth": info.bvh_depth, "num_rounds": info.num_rounds,
+            "qorigin": np.array(info.qorigin, np.float32), "qscale": np.array(info.qscale, np.float32),
+            "qnodes": qn[:info.num_nodes], "tris": tr[:info.num_tris]}
+
+
+def export_bvh_host(lights, spheres, triangles) -> dict:
+    """The tree hpt_scene_create would build and upload for these records, built on the host (no device needed)."""
+    lib = load_library()
+    lights = np.ascontiguousarray(lights, LIGHT)
+    spheres = np.ascontiguousarray(spheres, SPHERE)
+    triangles = np.ascontiguousarray(triangles, TRIANGLE)
+    return _export_bvh(lambda info, qn, qcap, tr, tcap: lib.hpt_bvh_export_host(
+        _vp(lights), len(lights), _vp(spheres), len(spheres), _vp(triangles), len(triangles), info, qn, qcap, tr, tcap))
 
 
 def probe_functions(records) -> np.ndarray:

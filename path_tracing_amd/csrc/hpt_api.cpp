@@ -1189,6 +1189,45 @@ int hpt_bdpt_render_wrapper(const void *lights, int nl, const void *spheres, int
     return rc;
 }
 
+int hpt_bvh_export_host(const void *lights, int nl, const void *spheres, int ns, const void *tris, int nt, hpt_bvh_info *info,
+                        void *qnodes_out, size_t qnodes_cap, void *tris_out, size_t tris_cap){
+    if(!info) return fail(HPT_ERR_INVALID, "null info");
+    HostScene hs;
+    const char *err = build_host_scene(lights, nl, spheres, ns, tris, nt, hs);
+    if(err && *err) return fail(HPT_ERR_INVALID, err);
+    info->num_nodes = (int32_t) hs.qnodes.size(); info->num_tris = (int32_t) hs.tris.size();
+    info->bvh_depth = hs.bvh_depth; info->num_rounds = ns + nl;
+    for(int a = 0; a < 3; ++a){ info->qorigin[a] = hs.qorigin[a]; info->qscale[a] = hs.qscale[a]; }
+    if(qnodes_out){
+        if(qnodes_cap < hs.qnodes.size() * sizeof(QBvhNode)) return fail(HPT_ERR_INVALID, "qnodes_out too small");
+        memcpy(qnodes_out, hs.qnodes.data(), hs.qnodes.size() * sizeof(QBvhNode));
+    }
+    if(tris_out){
+        if(tris_cap < hs.tris.size() * sizeof(DevTriangle)) return fail(HPT_ERR_INVALID, "tris_out too small");
+        memcpy(tris_out, hs.tris.data(), hs.tris.size() * sizeof(DevTriangle));
+    }
+    return HPT_OK;
+}
+
+int hpt_scene_export_bvh(const hpt_scene *s, hpt_bvh_info *info, void *qnodes_out, size_t qnodes_cap, void *tris_out, size_t tris_cap){
+    if(!s || !info) return fail(HPT_ERR_INVALID, "null argument");
+    if(int rcd = on_scene_device(s)) return rcd;
+    info->num_nodes = s->sd.num_nodes; info->num_tris = s->sd.num_tris;
+    info->bvh_depth = (int32_t) s->stats.bvh_depth; info->num_rounds = s->sd.num_rounds;
+    for(int a = 0; a < 3; ++a){ info->qorigin[a] = s->sd.qorigin[a]; info->qscale[a] = s->sd.qscale[a]; }
+    if(qnodes_out){
+        const size_t bytes = (size_t) s->sd.num_nodes * sizeof(QBvhNode);
+        if(qnodes_cap < bytes) return fail(HPT_ERR_INVALID, "qnodes_out too small");
+        HIP_TRY(hipMemcpy(qnodes_out, s->d_qnodes, bytes, hipMemcpyDeviceToHost));
+    }
+    if(tris_out){
+        const size_t bytes = (size_t) s->sd.num_tris * sizeof(DevTriangle);
+        if(tris_cap < bytes) return fail(HPT_ERR_INVALID, "tris_out too small");
+        if(bytes) HIP_TRY(hipMemcpy(tris_out, s->d_tris, bytes, hipMemcpyDeviceToHost));
+    }
+    return HPT_OK;
+}
+
 int hpt_trace_visibility(hpt_scene *s, const float *p1, const float *p2, int n, int flags, int32_t *vis_out){
     if(!s || !p1 || !p2 || !vis_out || n < 0) return fail(HPT_ERR_INVALID, "bad argument");
     if(n == 0) return HPT_OK;

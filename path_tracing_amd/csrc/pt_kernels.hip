@@ -886,7 +886,10 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                         float dz = fabsf(rd.z) > 1e-20f ? rd.z : copysignf(1e-20f, rd.z);
                         // box tests only have to be conservative: the 1-ulp hardware reciprocal is inside the
                         // 2e-6 slack of the slab test (the triangle tests below use exact arithmetic)
-                        ix = __builtin_amdgcn_rcpf(dx); iy = __builtin_amdgcn_rcpf(dy); iz = __builtin_amdgcn_rcpf(dz);
+                        // (the counting render divides exactly: its node and triangle tallies are then a function of the ray
+                        // and the tree alone, which the oracle's host walk of the exported tree reproduces to the last count)
+                        if(COUNT){ ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
+                        else { ix = __builtin_amdgcn_rcpf(dx); iy = __builtin_amdgcn_rcpf(dy); iz = __builtin_amdgcn_rcpf(dz); }
                         // quantised boxes: plane = qorigin + q * qscale, so t = q * (qscale * inv) + (qorigin - o) * inv
                         ox = (sc.qorigin[0] - ro.x) * ix; oy = (sc.qorigin[1] - ro.y) * iy; oz = (sc.qorigin[2] - ro.z) * iz;
                         ix *= sc.qscale[0]; iy *= sc.qscale[1]; iz *= sc.qscale[2];
