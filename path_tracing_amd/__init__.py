@@ -112,7 +112,8 @@ def load_library() -> C.CDLL:
                      "hpt_device_count", "hpt_multi_create", "hpt_multi_num_devices", "hpt_multi_set_groups",
                      "hpt_multi_render_pt", "hpt_multi_render_bdpt", "hpt_multi_get_timing", "hpt_wrapper_set_devices",
                      "hpt_probe_functions", "hpt_tonemap", "hpt_tonemap_host", "hpt_bvh_export_host", "hpt_scene_export_bvh"):
-            getattr(lib, name).restype = C.c_int
+            if hasattr(lib, name):          # (an older build loaded through HPT_LIBRARY for an A/B run lacks the newest entry points)
+                getattr(lib, name).restype = C.c_int
         lib.hpt_scene_destroy.restype = None
         lib.hpt_wrapper_cache_clear.restype = None
         lib.hpt_wrapper_cache_clear.argtypes = []

@@ -68,7 +68,7 @@ static_assert(sizeof(hpt_stats) == 248 && sizeof(hpt_params) == 40, "ABI records
 
 struct hpt_scene {
     SceneDev sd{};
-    BvhNode *d_nodes = nullptr; QBvhNode *d_qnodes = nullptr; DevTriangle *d_tris = nullptr; DevRound *d_rounds = nullptr;
+    BvhNode *d_nodes = nullptr; QBvhNode *d_qnodes = nullptr; WideNode *d_wnodes = nullptr; DevTriangle *d_tris = nullptr; DevRound *d_rounds = nullptr;
     DevMaterial *d_mats = nullptr; DevLight *d_lights = nullptr;
     float4 *d_tri_frames = nullptr;
     int device = 0;
@@ -90,6 +90,7 @@ struct hpt_scene {
         uint32_t *queue[2] = { nullptr, nullptr };   // path queues (ping-pong)
         uint32_t *squeue = nullptr;                  // shadow queue (path slots)
         uint32_t *lqueue[2] = { nullptr, nullptr };  // rays set aside by the first trace launch: closest-hit, shadow
+        uint32_t *deep_stack = nullptr;              // stack levels of the resume launch past its LDS share (launch_trace_resume)
         uint32_t *counters = nullptr; int n_counters = 0;
         uint32_t *h_count = nullptr;                 // pinned read-back word
     } pass[2];
@@ -127,9 +128,9 @@ using PassBuffers = hpt_scene::PassBuffers;
 void free_pass(PassBuffers &w){
     hipFree(w.pb.org_eta); hipFree(w.pb.dir_flags); hipFree(w.pb.thr); hipFree(w.pb.col); hipFree(w.pb.rng); hipFree(w.pb.hit);
     hipFree(w.sb.org_max); hipFree(w.sb.dir); hipFree(w.sb.contrib);
-    hipFree(w.queue[0]); hipFree(w.queue[1]); hipFree(w.squeue); hipFree(w.lqueue[0]); hipFree(w.lqueue[1]);
+    hipFree(w.queue[0]); hipFree(w.queue[1]); hipFree(w.squeue); hipFree(w.lqueue[0]); hipFree(w.lqueue[1]); hipFree(w.deep_stack);
     w.pb = PathBuf{}; w.sb = ShadowBuf{};
-    w.queue[0] = w.queue[1] = w.squeue = w.lqueue[0] = w.lqueue[1] = nullptr;
+    w.queue[0] = w.queue[1] = w.squeue = w.lqueue[0] = w.lqueue[1] = w.deep_stack = nullptr;
     w.cap_paths = 0;
 }
 
@@ -150,6 +151,7 @@ int ensure_pass(PassBuffers &w, size_t paths, int n_counters){
         HIP_TRY(hipMalloc((void **) &w.squeue, paths * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **) &w.lqueue[0], paths * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **) &w.lqueue[1], paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **) &w.deep_stack, resume_deep_stack_words() * sizeof(uint32_t)));
         w.cap_paths = paths;
     }
     if(n_counters > w.n_counters){
@@ -355,7 +357,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
 
     // one pass in flight on one pipeline
     struct Pass {
-        PathBuf pb; ShadowBuf sb; uint32_t *queue[2], *squeue, *lqueue[2]; uint32_t *counters, *h_count; hipStream_t st;
+        PathBuf pb; ShadowBuf sb; uint32_t *queue[2], *squeue, *lqueue[2], *deep_stack; uint32_t *counters, *h_count; hipStream_t st;
         int sthis = 0, cur = 0, pending_shadow = -1; uint32_t slots = 0; PrimaryGen primary{};
         uint32_t *qcnt = nullptr, *scnt = nullptr, *lecnt = nullptr, *lscnt = nullptr;
     };
@@ -365,6 +367,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         Pass &q = pipe[k];
         q.pb = w.pb; q.sb = w.sb; q.queue[0] = w.queue[0]; q.queue[1] = w.queue[1]; q.squeue = w.squeue;
         q.lqueue[0] = w.lqueue[0]; q.lqueue[1] = w.lqueue[1];
+        q.deep_stack = ((flags >> 18) & 1) ? nullptr : w.deep_stack;      // flags bits 16-31: development switches (bit 18: whole stack in LDS; bit 19: two levels in LDS; bit 20: binary resume launch; bits 21-28: its tuning)
         q.counters = w.counters; q.h_count = w.h_count; q.st = k == 0 ? stream : s->p2_stream;
     }
     for(Pass &q : pipe){
@@ -412,7 +415,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                            q.pending_shadow >= 0 ? &q.scnt[q.pending_shadow] : nullptr, q.slots, s->stack_levels, kflags, tuning, wc, &split, primary, cap); }
             if(split.budget > 0){
                 LaunchTimer t(s, q.st, timek, 4);
-                launch_trace_resume(q.st, s->sd, q.pb, q.sb, true, q.pending_shadow >= 0, q.slots, s->stack_levels, wc, split, primary, cap);
+                launch_trace_resume(q.st, s->sd, q.pb, q.sb, true, q.pending_shadow >= 0, q.slots, s->stack_levels, wc, split, primary, cap, q.deep_stack, ((flags >> 19) & 1) != 0, ((flags >> 20) & 1) == 0, (flags >> 21) & 0xFF);
             }
             q.pending_shadow = -1;
         }
@@ -456,7 +459,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                            s->stack_levels, kflags, tuning, wc, &split, nullptr, blind_groups); }
             if(split.budget > 0){
                 LaunchTimer t(s, q.st, timek, 4);
-                launch_trace_resume(q.st, s->sd, q.pb, q.sb, false, true, q.slots, s->stack_levels, wc, split, nullptr, blind_groups);
+                launch_trace_resume(q.st, s->sd, q.pb, q.sb, false, true, q.slots, s->stack_levels, wc, split, nullptr, blind_groups, q.deep_stack, ((flags >> 19) & 1) != 0, ((flags >> 20) & 1) == 0, (flags >> 21) & 0xFF);
             }
         }
         return HPT_OK;
@@ -818,6 +821,7 @@ int scene_upload(const HostScene &hs, const void *lights, int nl, const void *sp
     if(e == hipSuccess){ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount; }
     if(e == hipSuccess) e = upload(hs.nodes, &s->d_nodes);
     if(e == hipSuccess) e = upload(hs.qnodes, &s->d_qnodes);
+    if(e == hipSuccess) e = upload(hs.wnodes, &s->d_wnodes);
     if(e == hipSuccess) e = upload(hs.tris, &s->d_tris);
     if(e == hipSuccess) e = upload(hs.rounds, &s->d_rounds);
     if(e == hipSuccess) e = upload(hs.materials, &s->d_mats);
@@ -841,6 +845,7 @@ int scene_upload(const HostScene &hs, const void *lights, int nl, const void *sp
     s->sd.nodes = (const float4 *) s->d_nodes; s->sd.tris = (const float4 *) s->d_tris;
     s->sd.tri_frames = s->d_tri_frames;
     s->sd.qnodes = (const uint4 *) s->d_qnodes;
+    s->sd.wnodes = (const uint4 *) s->d_wnodes; s->sd.wide_depth = hs.wide_depth;
     for(int a = 0; a < 3; ++a){ s->sd.qorigin[a] = hs.qorigin[a]; s->sd.qscale[a] = hs.qscale[a]; }
     s->sd.rounds = s->d_rounds; s->sd.mats = s->d_mats; s->sd.lights = s->d_lights;
     s->sd.num_rounds = ns + nl; s->sd.num_spheres = ns; s->sd.num_lights = nl; s->sd.num_tris = nt;
@@ -895,7 +900,7 @@ void hpt_scene_destroy(hpt_scene *s){
     if(s->h_split) hipHostFree(s->h_split);
     if(s->ev_split) hipEventDestroy(s->ev_split);
     hipFree(s->d_local_own); hipFree(s->d_image_own);
-    hipFree(s->d_nodes); hipFree(s->d_qnodes); hipFree(s->d_tris); hipFree(s->d_rounds); hipFree(s->d_mats); hipFree(s->d_lights);
+    hipFree(s->d_nodes); hipFree(s->d_qnodes); hipFree(s->d_wnodes); hipFree(s->d_tris); hipFree(s->d_rounds); hipFree(s->d_mats); hipFree(s->d_lights);
     hipFree(s->d_tri_frames);
     free_bdpt(s);
     if(s->ev_start) hipEventDestroy(s->ev_start);

@@ -36,6 +36,13 @@ struct QBvhNode {
     uint32_t left, right;
 };
 
+// Four-wide twin of the tree (development: the resume launch's A/B), 64 B: the binary tree
+// collapsed greedily (the child with the largest box is opened until a node has four children or only leaves are left),
+// child boxes on the same 16-bit grid.  Words 0-3 x, 4-7 y, 8-11 z: lo(c0)|lo(c1)<<16, lo(c2)|lo(c3)<<16, hi(c0)|hi(c1)<<16,
+// hi(c2)|hi(c3)<<16 -- a ray picks the near and far planes of two children with one bit-select per word; words 12-15 the
+// child codes (leaf codes as in the binary tree, inner = index into the wide node array, kEmptyChild).
+struct WideNode { uint32_t w[16]; };
+
 struct DevTriangle {       // 48 B
     float v0[3]; uint32_t ordinal;   // reference scan ordinal (num_spheres + num_lights + input index)
     float e1[3]; uint32_t material;  // index into the material table
@@ -67,13 +74,15 @@ struct DevLight {          // 112 B
 };
 
 static_assert(sizeof(BvhNode) == 64 && sizeof(DevTriangle) == 48 && sizeof(DevRound) == 32, "layout");
-static_assert(sizeof(QBvhNode) == 32, "layout");
+static_assert(sizeof(QBvhNode) == 32 && sizeof(WideNode) == 64, "layout");
 static_assert(sizeof(DevMaterial) == 48 && sizeof(DevLight) == 112, "layout");
 
 // Host-side flattened scene, ready to upload.
 struct HostScene {
     std::vector<BvhNode> nodes;        // nodes[0] is the root (always an inner node)
     std::vector<QBvhNode> qnodes;      // same tree, quantised boxes
+    std::vector<WideNode> wnodes;      // four-wide collapse of it (development A/B)
+    int wide_depth = 0;
     float qorigin[3] = {0, 0, 0}, qscale[3] = {1, 1, 1};   // grid: coordinate = qorigin + q * qscale
     std::vector<DevTriangle> tris;     // leaf order
     std::vector<DevRound> rounds;      // spheres, then light balls

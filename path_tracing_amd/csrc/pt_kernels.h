@@ -9,6 +9,8 @@ namespace hpt {
 struct SceneDev {
     const float4 *nodes;        // BvhNode as 4 x float4
     const uint4 *qnodes;        // QBvhNode as 2 x uint4 (k_trace)
+    const uint4 *wnodes;        // WideNode as 4 x uint4 (development: four-wide resume launch)
+    int wide_depth;
     float qorigin[3], qscale[3];
     const float4 *tris;         // DevTriangle as 3 x float4, leaf order
     const float4 *tri_frames;   // per triangle 4 x float4: shading normal and both local frames (launch_tri_frames)
@@ -64,6 +66,11 @@ constexpr int kBlock = 256;
 constexpr uint32_t kLongChunk = 2048;
 constexpr int kLongRefillMin = 16;
 constexpr int kLongNodeMin = 8;
+constexpr int kResumeLdsLevels = 12; // stack levels of the resume launch kept in LDS when a deep-stack buffer is given (deeper: global memory)
+constexpr uint32_t kResumeMaxGroups = 8192;   // grid cap of the resume launch
+constexpr int kDeepLevels = 48;      // global-memory stack levels per lane of the resume launch (the four-wide walk stacks up to three children per step)
+constexpr int kWideRefillMin = 24;   // the same two thresholds for the four-wide resume launch (A/B grid 16/24/32 x 12/16/24 on configs 3 and 5)
+constexpr int kWideNodeMin = 16;
 constexpr int kTraceBudget = 6;      // node steps a ray gets in the first trace launch before it is set aside
 constexpr int kTopLevels = 6;        // a budget of at most this many steps keeps a ray among the first kTopNodes nodes
 constexpr int kTopNodes = 64;        // (breadth-first order, scene_build.cpp): 2^kTopLevels - 1 = 63 nodes of 32 B, staged in LDS
@@ -89,7 +96,10 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
                   const TraceSplit *split = nullptr, const PrimaryGen *primary = nullptr, uint32_t max_groups = 0);
 void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
                          uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split,
-                         const PrimaryGen *primary = nullptr, uint32_t max_groups = 0);
+                         const PrimaryGen *primary = nullptr, uint32_t max_groups = 0, uint32_t *deep_stack = nullptr,
+                         bool tiny_lds_share = false, bool wide = false, int dev_tuning = 0);
+// words of the buffer launch_trace_resume's deep_stack needs (one column per lane of its largest grid)
+size_t resume_deep_stack_words();
 // fills frames[4 * num_tris] from tris (once per scene)
 void launch_tri_frames(hipStream_t s, const float4 *tris, int num_tris, float4 *frames);
 void launch_resolve(hipStream_t s, const Tiling &tl, PathBuf pb, float4 *accum, int samples_this_pass);

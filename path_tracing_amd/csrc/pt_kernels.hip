@@ -31,6 +31,12 @@ HPT_DEV uint32_t f2u(float f){ return __float_as_uint(f); }
 HPT_DEV float u2f(uint32_t u){ return __uint_as_float(u); }
 HPT_DEV f3 xyz(float4 v){ return mk3(v.x, v.y, v.z); }
 
+// (m & a) | (~m & b) in one instruction, and the two 16-bit halves of a word as floats (SDWA conversions): the compiler
+// expands the first into three and masks before converting the low half
+HPT_DEV uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b){ uint32_t r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
+HPT_DEV float lo16f(uint32_t w){ float r; asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(w)); return r; }
+HPT_DEV float hi16f(uint32_t w){ float r; asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(w)); return r; }
+
 // ---- wave64 queue push: ballot, mbcnt prefix, one atomic per wave on a workgroup-local LDS counter ----
 HPT_DEV uint32_t lds_push(bool want, uint32_t *lds_counter){
     unsigned long long mask = __ballot(want);
@@ -778,6 +784,19 @@ void k_tonemap(const float *linear, uint32_t *out_words, unsigned long long num_
 //   same with one cursor per 128-B line (82 VGPRs) ................................... 47.5
 // Chunk size: 256 -> 47.3, 512 -> 45.5, 1024 -> 49.6, 2048 -> 59.3 (long chunks leave the tail of
 // a launch to a few workgroups); refill threshold 8 -> 51.0, 16 -> 49.6, 32 -> 48.6, 48 -> 48.0.
+// k_trace's registers are fitted to eight waves per SIMD -- vector AND scalar: left alone the compiler takes 106 SGPRs, and
+// more than 96 cap a CU at six 256-thread workgroups whatever the vector registers allow (80 with this attribute, the
+// rest spilled to lanes of a VGPR).  Measured against the unconstrained build: first launch 11.37 -> 11.00 ms, resume
+// 8.14 -> 7.70 per 64-spp pass of config 3, 14.00 -> 13.46 on the 1 M-triangle shape.  `make variant EXTRA=-DHPT_TRACE_WAVES=0`
+// builds without it, =7 with seven.
+#ifndef HPT_TRACE_WAVES
+#define HPT_TRACE_WAVES 8
+#endif
+#if HPT_TRACE_WAVES > 0
+#define HPT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(HPT_TRACE_WAVES, 8)))
+#else
+#define HPT_TRACE_ATTR
+#endif
 constexpr int kTraceChunk = 1024;     // rays per workgroup (with the branch-free node step: 512 -> 37.6 ms, 768 -> 36.5, 1024 -> 36.5, 1280 -> 36.1, 1536 -> 36.7, 2048 -> 38.4)
 constexpr uint32_t kDoneCode = 0xFFFFFFFEu;   // leaf-flagged code a finished walk parks in cur
 constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
@@ -785,15 +804,21 @@ constexpr int kNodeMin = 4;           // fewer lanes than this still walking nod
                                       // (A/B: off 42.1 ms, 2: 39.9, 4: 39.4, 8: 40.2, 16: 41.3, 32: 43.2)
 constexpr uint32_t kTraceShortQueue = 1u << 20;   // below this many rays a workgroup takes 256 instead of kTraceChunk
 
-template <bool ANY, bool COUNT, bool RESUME, bool TOP, bool PRIMARY>
+// LDSK > 0: only the first LDSK stack levels of a lane live in LDS, deeper ones in its column of `deep` (global memory,
+// one column per lane of the grid, `deep_stride` words apart): the resume launch walks the long rays with the whole tree
+// depth as its stack bound (22 KB of LDS per workgroup at depth 21, 27 KB at 26: five or six workgroups per CU), while a
+// ray rarely holds more than a dozen pending subtrees
+template <bool ANY, bool COUNT, bool RESUME, bool TOP, bool PRIMARY, int LDSK, bool WIDE>
 HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uint32_t *queue,
                          uint32_t end, uint32_t *stk, uint32_t *s_next, int refill_min, int node_min, WorkCounters *wc,
-                         uint32_t budget, uint32_t *s_long, uint32_t *s_nlong, const uint4 *top, const PrimaryGen &pg){
+                         uint32_t budget, uint32_t *s_long, uint32_t *s_nlong, const uint4 *top, const PrimaryGen &pg,
+                         uint32_t *deep, uint32_t deep_stride){
     bool active = false, exhausted = false;
     uint32_t path = 0u, cur = 0u, steps = 0u;
     int sp = 0;
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
     float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
+    uint32_t mx = 0u, my = 0u, mz = 0u;          // WIDE: all ones where the ray runs against the axis (its near plane is a box's upper one)
     float tmax = 0.0f, limit = 0.0f, best_t = 1e20f;
     uint32_t best_prim = kHitMiss, best_ord = 0xFFFFFFFFu;
     unsigned long long n_lane_steps = 0, n_wave_steps = 0, n_boxes = 0, n_tris = 0, n_rays = 0, n_leaf_lane = 0, n_leaf_wave = 0;
@@ -893,6 +918,7 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                         // quantised boxes: plane = qorigin + q * qscale, so t = q * (qscale * inv) + (qorigin - o) * inv
                         ox = (sc.qorigin[0] - ro.x) * ix; oy = (sc.qorigin[1] - ro.y) * iy; oz = (sc.qorigin[2] - ro.z) * iz;
                         ix *= sc.qscale[0]; iy *= sc.qscale[1]; iz *= sc.qscale[2];
+                        if(WIDE){ mx = ix < 0.0f ? 0xFFFFFFFFu : 0u; my = iy < 0.0f ? 0xFFFFFFFFu : 0u; mz = iz < 0.0f ? 0xFFFFFFFFu : 0u; }
                         cur = 0u; sp = 0; steps = 0u;
                         active = true;
                     }
@@ -918,6 +944,59 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                 if((int) lane == __ffsll((long long) __ballot(true)) - 1) n_wave_steps += 64;   // one wave trip
             }
             if(!RESUME) steps += 1u;
+            if(WIDE){
+                // four-wide step (development A/B): four child boxes from one 64-B node; the nearest hit child is entered, the
+                // other hit children are stacked in slot order (ordering them too buys 0.3 % fewer steps on the benchmark
+                // meshes: scripts/micro/bvh4_steps.cpp).  t = q * i + o is monotone in q, so the near plane of an axis is the
+                // lower one when i >= 0 and the upper one otherwise: one bit-select per word picks it for two children.
+                const uint4 *n = sc.wnodes + (size_t) cur * 4;
+                const uint4 qx = n[0], qy = n[1], qz = n[2], qc = n[3];
+                const uint32_t nx01 = bit_select(mx, qx.z, qx.x), nx23 = bit_select(mx, qx.w, qx.y), fx01 = bit_select(mx, qx.x, qx.z), fx23 = bit_select(mx, qx.y, qx.w);
+                const uint32_t ny01 = bit_select(my, qy.z, qy.x), ny23 = bit_select(my, qy.w, qy.y), fy01 = bit_select(my, qy.x, qy.z), fy23 = bit_select(my, qy.y, qy.w);
+                const uint32_t nz01 = bit_select(mz, qz.z, qz.x), nz23 = bit_select(mz, qz.w, qz.y), fz01 = bit_select(mz, qz.x, qz.z), fz23 = bit_select(mz, qz.y, qz.w);
+                const float tn0 = fmaxf(fmaxf(fmaf(lo16f(nx01), ix, ox), fmaf(lo16f(ny01), iy, oy)), fmaxf(fmaf(lo16f(nz01), iz, oz), 0.0f));
+                const float tf0 = fminf(fminf(fmaf(lo16f(fx01), ix, ox), fmaf(lo16f(fy01), iy, oy)), fminf(fmaf(lo16f(fz01), iz, oz), limit));
+                const float tn1 = fmaxf(fmaxf(fmaf(hi16f(nx01), ix, ox), fmaf(hi16f(ny01), iy, oy)), fmaxf(fmaf(hi16f(nz01), iz, oz), 0.0f));
+                const float tf1 = fminf(fminf(fmaf(hi16f(fx01), ix, ox), fmaf(hi16f(fy01), iy, oy)), fminf(fmaf(hi16f(fz01), iz, oz), limit));
+                const float tn2 = fmaxf(fmaxf(fmaf(lo16f(nx23), ix, ox), fmaf(lo16f(ny23), iy, oy)), fmaxf(fmaf(lo16f(nz23), iz, oz), 0.0f));
+                const float tf2 = fminf(fminf(fmaf(lo16f(fx23), ix, ox), fmaf(lo16f(fy23), iy, oy)), fminf(fmaf(lo16f(fz23), iz, oz), limit));
+                const float tn3 = fmaxf(fmaxf(fmaf(hi16f(nx23), ix, ox), fmaf(hi16f(ny23), iy, oy)), fmaxf(fmaf(hi16f(nz23), iz, oz), 0.0f));
+                const float tf3 = fminf(fminf(fmaf(hi16f(fx23), ix, ox), fmaf(hi16f(fy23), iy, oy)), fminf(fmaf(hi16f(fz23), iz, oz), limit));
+                // key = entry distance with the slot number in its two lowest bits (distances are >= 0: their bit patterns order
+                // like the values), all ones for a child that is missed or absent
+                const uint32_t k0 = (tn0 <= tf0 * 1.000002f && qc.x != kEmptyChild) ? (f2u(tn0) & ~3u) : 0xFFFFFFFFu;
+                const uint32_t k1 = (tn1 <= tf1 * 1.000002f && qc.y != kEmptyChild) ? ((f2u(tn1) & ~3u) | 1u) : 0xFFFFFFFFu;
+                const uint32_t k2 = (tn2 <= tf2 * 1.000002f && qc.z != kEmptyChild) ? ((f2u(tn2) & ~3u) | 2u) : 0xFFFFFFFFu;
+                const uint32_t k3 = (tn3 <= tf3 * 1.000002f && qc.w != kEmptyChild) ? ((f2u(tn3) & ~3u) | 3u) : 0xFFFFFFFFu;
+                const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+                const bool any = kmin != 0xFFFFFFFFu;
+                const uint32_t slot = kmin & 3u;
+                uint32_t near = qc.x;
+                near = slot == 1u ? qc.y : near; near = slot == 2u ? qc.z : near; near = slot == 3u ? qc.w : near;
+                // stacked: hit and not the nearest, i.e. kmin < key < all ones -- one add and one unsigned compare per child
+                const uint32_t c1 = ~kmin, c2 = c1 - 1u;
+                const int e0 = (k0 + c1 < c2) ? 1 : 0, e1 = (k1 + c1 < c2) ? 1 : 0, e2 = (k2 + c1 < c2) ? 1 : 0, e3 = (k3 + c1 < c2) ? 1 : 0;
+                uint32_t top;
+                int p = sp;
+                if(sp + 3 < LDSK){
+                    // every level this step can touch is in LDS; a child that is not stacked is written to the spare level
+                    top = stk[(sp > 0 ? sp - 1 : 0) * kBlock];
+                    stk[(e0 ? p : LDSK) * kBlock] = qc.x; p += e0;
+                    stk[(e1 ? p : LDSK) * kBlock] = qc.y; p += e1;
+                    stk[(e2 ? p : LDSK) * kBlock] = qc.z; p += e2;
+                    stk[(e3 ? p : LDSK) * kBlock] = qc.w; p += e3;
+                } else {
+                    auto level = [&](int l) -> uint32_t * { return l < LDSK ? stk + l * kBlock : deep + (size_t) (l - LDSK) * deep_stride; };
+                    top = *level(sp > 0 ? sp - 1 : 0);
+                    if(e0){ *level(p) = qc.x; ++p; }
+                    if(e1){ *level(p) = qc.y; ++p; }
+                    if(e2){ *level(p) = qc.z; ++p; }
+                    if(e3){ *level(p) = qc.w; ++p; }
+                }
+                cur = any ? near : (sp > 0 ? top : kDoneCode);
+                sp = any ? p : (sp > 0 ? sp - 1 : 0);
+                continue;
+            }
             // TOP: a ray with a budget of kTopLevels node steps only ever reaches nodes of depth < kTopLevels, which the
             // breadth-first node order puts among the first kTopNodes: those sit in LDS (staged once per workgroup)
             const uint4 *n = TOP ? top + cur * 2u : sc.qnodes + (size_t) cur * 2;
@@ -941,8 +1020,14 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
             // it, then pick by selects.  The stack has one spare level for the unconditional store.
             bool any = hl || hr, both = hl && hr;
             bool left_first = hl && (!hr || ln <= rn);
-            uint32_t top = stk[(sp > 0 ? sp - 1 : 0) * kBlock];
-            stk[sp * kBlock] = left_first ? rc : lc;
+            uint32_t top;
+            if(LDSK > 0 && sp >= LDSK){                  // rare: this lane's stack has grown past its LDS share
+                top = sp > LDSK ? deep[(size_t) (sp - 1 - LDSK) * deep_stride] : stk[(LDSK - 1) * kBlock];
+                deep[(size_t) (sp - LDSK) * deep_stride] = left_first ? rc : lc;
+            } else {
+                top = stk[(sp > 0 ? sp - 1 : 0) * kBlock];
+                stk[sp * kBlock] = left_first ? rc : lc;
+            }
             uint32_t near = left_first ? lc : rc;
             cur = any ? near : (sp > 0 ? top : kDoneCode);
             sp = any ? sp + (both ? 1 : 0) : (sp > 0 ? sp - 1 : 0);
@@ -975,7 +1060,10 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                     }
                 }
                 if(ANY && blocked) finished = true;                   // occluded: no contribution
-                else if(sp > 0){ --sp; cur = stk[sp * kBlock]; }
+                else if(sp > 0){
+                    --sp;
+                    cur = (LDSK > 0 && sp >= LDSK) ? deep[(size_t) (sp - LDSK) * deep_stride] : stk[sp * kBlock];
+                }
                 else finished = true;
             }
             if(finished){
@@ -1017,11 +1105,11 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
 // is the same (closest hit with the ordinal tie-break, or the occlusion boolean, of the same ray).
 struct LongQueues { uint32_t *equeue, *ecount, *squeue, *scount; uint32_t budget; };
 
-template <bool COUNT, bool RESUME, bool TOP, bool PRIMARY>
-__global__ __launch_bounds__(kBlock)
+template <bool COUNT, bool RESUME, bool TOP, bool PRIMARY, int LDSK, bool WIDE>
+__global__ __launch_bounds__(kBlock) HPT_TRACE_ATTR
 void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, const uint32_t *ecount_ptr,
              const uint32_t *squeue, const uint32_t *scount_ptr, uint32_t chunk_rays, int refill_min, int node_min,
-             int stack_words, LongQueues lq, WorkCounters *wc, PrimaryGen pg){
+             int stack_words, LongQueues lq, WorkCounters *wc, PrimaryGen pg, uint32_t *deep){
     extern __shared__ uint32_t s_dyn_stack[];        // [stack level][lane], sized by the BVH depth; then the long-ray list
     __shared__ uint32_t s_next, s_nlong, s_gbase;
     __shared__ uint4 s_top[TOP ? kTopNodes * 2 : 1];  // the top of the quantised tree (first launch of a split step)
@@ -1045,10 +1133,12 @@ void k_trace(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *equeue, cons
         uint32_t end = begin + csize < total ? begin + csize : total;
         if(threadIdx.x == 0){ s_next = begin; s_nlong = 0u; }
         __syncthreads();
-        if(shadow) trace_chunk<true, COUNT, RESUME, TOP, false>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
-                                                                lq.budget, s_long, &s_nlong, s_top, pg);
-        else trace_chunk<false, COUNT, RESUME, TOP, PRIMARY>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
-                                                             lq.budget, s_long, &s_nlong, s_top, pg);
+        uint32_t *deep_lane = LDSK > 0 ? deep + (size_t) blockIdx.x * kBlock + threadIdx.x : nullptr;
+        const uint32_t deep_stride = gridDim.x * kBlock;
+        if(shadow) trace_chunk<true, COUNT, RESUME, TOP, false, LDSK, WIDE>(sc, pb, sb, squeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
+                                                                      lq.budget, s_long, &s_nlong, s_top, pg, deep_lane, deep_stride);
+        else trace_chunk<false, COUNT, RESUME, TOP, PRIMARY, LDSK, WIDE>(sc, pb, sb, equeue, end, s_dyn_stack + threadIdx.x, &s_next, refill_min, node_min, wc,
+                                                                   lq.budget, s_long, &s_nlong, s_top, pg, deep_lane, deep_stride);
         __syncthreads();
         if(!RESUME && lq.budget != 0u){
             uint32_t n = s_nlong;
@@ -1233,8 +1323,8 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
     const bool top = lq.budget != 0u && lq.budget <= (uint32_t) kTopLevels && !(tuning & 0x80);       // tuning bit 7: node fetches from global memory (A/B)
     PrimaryGen none{};
     const PrimaryGen &pg = primary ? *primary : none;
-#define HPT_LAUNCH_TRACE(C, T, P) hipLaunchKernelGGL((k_trace<C, false, T, P>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, \
-                                                     scount, chunk, refill_min, node_min, stack_words, lq, wc, pg)
+#define HPT_LAUNCH_TRACE(C, T, P) hipLaunchKernelGGL((k_trace<C, false, T, P, 0, false>), dim3(g), dim3(kBlock), lds, s, sc, pb, sb, equeue, ecount, squeue, \
+                                                     scount, chunk, refill_min, node_min, stack_words, lq, wc, pg, (uint32_t *) nullptr)
     if(count) HPT_LAUNCH_TRACE(true, false, false);
     else if(top && primary) HPT_LAUNCH_TRACE(false, true, true);
     else if(top) HPT_LAUNCH_TRACE(false, true, false);
@@ -1247,29 +1337,61 @@ void launch_trace(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, c
 // the device, so a fixed grid walks the chunks.
 void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBuf sb, bool extend, bool shadow,
                          uint32_t max_items, int stack_levels, WorkCounters *wc, const TraceSplit &split, const PrimaryGen *primary,
-                         uint32_t max_groups){
+                         uint32_t max_groups, uint32_t *deep_stack, bool tiny_lds_share, bool wide, int dev_tuning){
     if(!extend && !shadow) return;
     if(stack_levels < 1) stack_levels = 1;
     if(stack_levels > kStackDepth) stack_levels = kStackDepth;
-    int stack_words = (stack_levels + 1) * kBlock;
+    // deep_stack: the lanes' stack levels past kResumeLdsLevels live in global memory (resume_deep_stack_words()); a tree
+    // that is no deeper keeps the plain LDS stack
+    // (tiny_lds_share: two levels in LDS, so that the tests walk the global-memory levels on every ray)
+    const int lds_levels = tiny_lds_share ? 2 : kResumeLdsLevels;
+    const bool spill = deep_stack != nullptr && stack_levels > lds_levels;
+    int stack_words = ((spill ? lds_levels : stack_levels) + 1) * kBlock;
     // every ray of this launch is a long one: lanes refill sooner, a workgroup takes more rays (a lane
     // gets ~8 rays, which evens out their lengths) and the leaf phase waits for fewer stragglers
-    const uint32_t chunk2 = kLongChunk; const int refill2 = kLongRefillMin, node_min2 = kLongNodeMin;
+    uint32_t chunk2 = kLongChunk; int refill2 = kLongRefillMin, node_min2 = kLongNodeMin;
+    {   // development sweeps (hpt_params.flags bits 21-28): refill threshold, early-leaf-break threshold, chunk
+        static const int refill_tab[8] = { 0, 8, 16, 24, 32, 40, 48, 56 }, node_tab[8] = { 0, 1, 2, 4, 12, 16, 24, 32 };
+        static const uint32_t chunk_tab[4] = { 0u, 1024u, 4096u, 512u };
+        if(dev_tuning & 7) refill2 = refill_tab[dev_tuning & 7];
+        if((dev_tuning >> 3) & 7) node_min2 = node_tab[(dev_tuning >> 3) & 7];
+        if((dev_tuning >> 6) & 3) chunk2 = chunk_tab[(dev_tuning >> 6) & 3];
+    }
     uint32_t per = (max_items + kBlock - 1) / kBlock;
     uint64_t g = (uint64_t) per * ((extend ? 1u : 0u) + (shadow ? 1u : 0u));
-    uint32_t g2 = g < 8192u ? (uint32_t) (g < 1u ? 1u : g) : 8192u;
+    uint32_t g2 = g < kResumeMaxGroups ? (uint32_t) (g < 1u ? 1u : g) : kResumeMaxGroups;
     if(max_groups != 0u && g2 > max_groups) g2 = max_groups;          // blind tail iterations (HPT_FLAG_NO_HOST_WAIT)
     LongQueues none{};
     PrimaryGen no_primary{};
-    if(primary && extend)
-        hipLaunchKernelGGL((k_trace<false, true, false, true>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
-                           split.equeue, split.ecount, shadow ? split.squeue : nullptr, shadow ? split.scount : nullptr, chunk2, refill2,
-                           node_min2, stack_words, none, wc, *primary);
-    else
-        hipLaunchKernelGGL((k_trace<false, true, false, false>), dim3(g2), dim3(kBlock), (size_t) stack_words * sizeof(uint32_t), s, sc, pb, sb,
-                           extend ? split.equeue : nullptr, extend ? split.ecount : nullptr, shadow ? split.squeue : nullptr,
-                           shadow ? split.scount : nullptr, chunk2, refill2, node_min2, stack_words, none, wc, no_primary);
+    const size_t lds = (size_t) stack_words * sizeof(uint32_t);
+    const uint32_t *eq = extend ? split.equeue : nullptr, *ec = extend ? split.ecount : nullptr;
+    const uint32_t *sq = shadow ? split.squeue : nullptr, *scn = shadow ? split.scount : nullptr;
+#define HPT_LAUNCH_RESUME(P, K, W, PG) hipLaunchKernelGGL((k_trace<false, true, false, P, K, W>), dim3(g2), dim3(kBlock), lds, s, sc, pb, sb, eq, ec, sq, scn, \
+                                                          chunk2, refill2, node_min2, stack_words, none, wc, PG, deep_stack)
+    // the long rays walk the four-wide twin of the tree (up to three children stacked per step: needs the deep-stack buffer);
+    // `wide` false = the binary walk (development A/B, and scenes whose wide tree would outgrow the stack)
+    if(wide && deep_stack && sc.wnodes && 3 * sc.wide_depth + 2 <= lds_levels + kDeepLevels){
+        stack_words = (lds_levels + 1) * kBlock;
+        const size_t lds = (size_t) stack_words * sizeof(uint32_t);
+        if(!(dev_tuning & 7)) refill2 = kWideRefillMin;
+        if(!((dev_tuning >> 3) & 7)) node_min2 = kWideNodeMin;
+        if(primary && extend){ if(tiny_lds_share) HPT_LAUNCH_RESUME(true, 2, true, *primary); else HPT_LAUNCH_RESUME(true, kResumeLdsLevels, true, *primary); }
+        else { if(tiny_lds_share) HPT_LAUNCH_RESUME(false, 2, true, no_primary); else HPT_LAUNCH_RESUME(false, kResumeLdsLevels, true, no_primary); }
+        return;
+    }
+    if(primary && extend){
+        if(spill && tiny_lds_share) HPT_LAUNCH_RESUME(true, 2, false, *primary);
+        else if(spill) HPT_LAUNCH_RESUME(true, kResumeLdsLevels, false, *primary);
+        else HPT_LAUNCH_RESUME(true, 0, false, *primary);
+    } else {
+        if(spill && tiny_lds_share) HPT_LAUNCH_RESUME(false, 2, false, no_primary);
+        else if(spill) HPT_LAUNCH_RESUME(false, kResumeLdsLevels, false, no_primary);
+        else HPT_LAUNCH_RESUME(false, 0, false, no_primary);
+    }
+#undef HPT_LAUNCH_RESUME
 }
+
+size_t resume_deep_stack_words(){ return (size_t) kDeepLevels * kResumeMaxGroups * kBlock; }
 
 void launch_tri_frames(hipStream_t s, const float4 *tris, int num_tris, float4 *frames){
     if(num_tris <= 0) return;

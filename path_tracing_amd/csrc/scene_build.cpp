@@ -333,6 +333,49 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
         }
     }
     if(hs.bvh_depth > kMaxBvhDepth) return "internal error: BVH deeper than the traversal stack";
+    {   // four-wide twin: greedy collapse of the binary tree, breadth-first numbering, same quantised child boxes
+        struct Kid { const float *mn, *mx; uint32_t code; };
+        auto half_area = [](const Kid &k){ float dx = k.mx[0] - k.mn[0], dy = k.mx[1] - k.mn[1], dz = k.mx[2] - k.mn[2]; return dx * dy + dy * dz + dz * dx; };
+        auto qlo = [&](float v, int a){ double q = std::floor(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) - 1.0; return (uint32_t) std::min(65535.0, std::max(0.0, q)); };
+        auto qhi = [&](float v, int a){ double q = std::ceil(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) + 1.0; return (uint32_t) std::min(65535.0, std::max(0.0, q)); };
+        std::vector<uint32_t> todo{0u};            // binary node each wide node was collapsed from
+        std::vector<int> depth{1};
+        hs.wnodes.clear(); hs.wnodes.emplace_back();
+        for(size_t qi = 0; qi < todo.size(); ++qi){
+            Kid kids[4]; int nk = 0;
+            auto open = [&](uint32_t idx){
+                const BvhNode &b = hs.nodes[idx];
+                if(b.left != kEmptyChild) kids[nk++] = Kid{ b.lmin, b.lmax, b.left };
+                if(b.right != kEmptyChild) kids[nk++] = Kid{ b.rmin, b.rmax, b.right };
+            };
+            open(todo[qi]);
+            while(nk < 4){
+                int best = -1; float ba = -1.0f;
+                for(int k = 0; k < nk; ++k) if(!(kids[k].code & kLeafFlag)){ float a = half_area(kids[k]); if(a > ba){ ba = a; best = k; } }
+                if(best < 0) break;
+                // an inner binary node has two children at most: opening one replaces it by them (nk grows by one at most)
+                uint32_t c = kids[best].code;
+                kids[best] = kids[nk - 1]; --nk;
+                open(c);
+            }
+            WideNode w;
+            uint32_t lo[3][4], hi[3][4], code[4];
+            for(int k = 0; k < 4; ++k){
+                if(k < nk){
+                    for(int a = 0; a < 3; ++a){ lo[a][k] = qlo(kids[k].mn[a], a); hi[a][k] = qhi(kids[k].mx[a], a); }
+                    if(kids[k].code & kLeafFlag) code[k] = kids[k].code;
+                    else { code[k] = (uint32_t) todo.size(); todo.push_back(kids[k].code); depth.push_back(depth[qi] + 1); hs.wnodes.emplace_back(); }
+                } else { for(int a = 0; a < 3; ++a){ lo[a][k] = 65535u; hi[a][k] = 0u; } code[k] = kEmptyChild; }
+            }
+            for(int a = 0; a < 3; ++a){
+                w.w[a * 4 + 0] = lo[a][0] | (lo[a][1] << 16); w.w[a * 4 + 1] = lo[a][2] | (lo[a][3] << 16);
+                w.w[a * 4 + 2] = hi[a][0] | (hi[a][1] << 16); w.w[a * 4 + 3] = hi[a][2] | (hi[a][3] << 16);
+            }
+            for(int k = 0; k < 4; ++k) w.w[12 + k] = code[k];
+            hs.wnodes[qi] = w;
+            hs.wide_depth = std::max(hs.wide_depth, depth[qi]);
+        }
+    }
 
     hs.tris.resize(nt);
     for(int s = 0; s < nt; ++s){

@@ -80,7 +80,7 @@ int main(int argc, char **argv){
     std::mt19937 rng(7); std::uniform_real_distribution<float> U(0.0f, 1.0f);
     std::vector<double> cdf((size_t) hs.num_tris); double acc = 0;
     for(int i = 0; i < hs.num_tris; ++i){ const DevTriangle &t = hs.tris[(size_t) i]; V c = cross(V{t.e1[0], t.e1[1], t.e1[2]}, V{t.e2[0], t.e2[1], t.e2[2]}); acc += 0.5 * std::sqrt(dot(c, c)); cdf[(size_t) i] = acc; }
-    unsigned long long s2 = 0, s4 = 0, b2 = 0, b4 = 0, t2 = 0, t4 = 0, long2 = 0, long4 = 0, nlong = 0, max2 = 0, max4 = 0;
+    unsigned long long s2 = 0, s4 = 0, b2 = 0, b4 = 0, t2 = 0, t4 = 0, long2 = 0, long4 = 0, nlong = 0, max2 = 0, max4 = 0, s4u = 0, t4u = 0, long4u = 0;
     std::vector<uint32_t> stk(256);
     for(int r = 0; r < nr; ++r){
         double pick = U(rng) * acc; int ti = (int) (std::lower_bound(cdf.begin(), cdf.end(), pick) - cdf.begin()); ti = std::min(ti, hs.num_tris - 1);
@@ -119,11 +119,25 @@ int main(int argc, char **argv){
               cur = nd.c[idx[0]].code;
           } }
         s4 += steps4; max4 = std::max(max4, steps4);
-        if(steps > 6){ ++nlong; long2 += steps; long4 += steps4; }
+        // 4-wide, cheaper ordering: the nearest hit child is entered, the other hit children are stacked in slot order
+        unsigned long long steps4u = 0; { float limit = 1e20f; int sp = 0; uint32_t cur = 0;
+          for(;;){
+              if(cur & kLeafFlag){ leaf(cur, limit, t4u); if(sp == 0) break; cur = stk[(size_t) --sp]; continue; }
+              ++steps4u; const Node4 &nd = N4[cur];
+              float tn[4]; int idx[4], nh = 0, best = -1;
+              for(int k = 0; k < nd.n; ++k){ float x; if(slab(nd.c[k].mn, nd.c[k].mx, o, inv, limit, x)){ tn[nh] = x; idx[nh] = k; if(best < 0 || x < tn[best]) best = nh; ++nh; } }
+              if(nh == 0){ if(sp == 0) break; cur = stk[(size_t) --sp]; continue; }
+              for(int i = 0; i < nh; ++i) if(i != best) stk[(size_t) sp++] = nd.c[idx[i]].code;
+              cur = nd.c[idx[best]].code;
+          } }
+        s4u += steps4u;
+        if(steps > 6){ ++nlong; long2 += steps; long4 += steps4; long4u += steps4u; }
     }
     printf("rays %d: binary %.2f node steps per ray (%.2f boxes, %.2f triangle tests, max %llu); 4-wide %.2f steps (%.2f boxes, %.2f triangle tests, max %llu)\n",
            nr, (double) s2 / nr, (double) b2 / nr, (double) t2 / nr, max2, (double) s4 / nr, (double) b4 / nr, (double) t4 / nr, max4);
     printf("steps ratio 4-wide / binary: %.3f; boxes ratio %.3f\n", (double) s4 / s2, (double) b4 / b2);
+    printf("4-wide with only the nearest child ordered: %.2f steps per ray (x %.3f of the fully ordered walk), %.2f triangle tests; long rays %.2f steps\n",
+           (double) s4u / nr, (double) s4u / std::max(1ull, s4), (double) t4u / nr, (double) long4u / std::max(1ull, nlong));
     printf("rays with more than 6 binary steps: %.1f %%, binary %.2f steps, 4-wide %.2f (ratio %.3f)\n", 100.0 * nlong / nr, (double) long2 / std::max(1ull, nlong), (double) long4 / std::max(1ull, nlong), (double) long4 / std::max(1ull, long2));
     return 0;
 }

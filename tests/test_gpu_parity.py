@@ -394,6 +394,28 @@ def hpt_default_budget():
     return 6          # kTraceBudget, csrc/pt_kernels.h
 
 
+def test_resume_launch_layouts(hpt, sio, oracle_mod):
+    """The resume launch walks the four-wide twin of the tree, 12 stack levels per lane in LDS and deeper ones in global
+    memory.  Development switches force the other forms -- two levels in LDS (flags bit 19: every long ray then uses
+    the global-memory levels), the binary walk (bit 20) with 12 levels, the whole stack (bit 18) or two levels in LDS --
+    on a mesh of 30 000 triangles and on the incoherent random-triangle cloud, with the default budget and with a
+    budget of 1 (practically every ray resumes); every form is the oracle's image bit for bit."""
+    W18, W19, W20 = 1 << 18, 1 << 19, 1 << 20
+    for L, sp, tr in (sio.cornell_with_sphere(30000), sio.cornell_random_triangles(20000)):
+        cam = sio.make_camera(sio.CORNELL_EYE, sio.CORNELL_LOOK, sio.CORNELL_UP, 50.0, 80, 64)
+        bvh = hpt.export_bvh_host(L, sp, tr)
+        assert bvh["bvh_depth"] > 12
+        ref, _ = oracle_mod.pt_render(L, sp, tr, cam, 80, 64, 4, 3, seed=9, bvh=bvh)
+        with hpt.Scene(L, sp, tr) as scene:
+            for dev in (0, W19, W20, W20 | W18, W20 | W19):
+                for budget in (6, 1):
+                    p = hpt.make_params(seed=9, flags=dev | hpt.FLAG_TIME_KERNELS)
+                    p.reserved = budget << 1
+                    img = scene.render_pt(cam, 80, 64, 4, 3, p)
+                    assert scene.stats()["n_resume"] > 0
+                    assert_parity(img, ref)
+
+
 def test_split_is_dropped_for_scenes_whose_rays_are_all_long(hpt, sio, oracle_mod):
     """With the default budget the renderer reads back (asynchronously) how many rays the split set aside;
     when that is most of them the next frames of the scene use single-launch trace steps.  Same image."""
