@@ -58,7 +58,11 @@ struct DevBuf {              // device allocation released on every return path
 };
 
 struct TimedLaunch { hipEvent_t a, b; int cls; };
-constexpr int kSplitHold = 15;
+// Frames a scene whose rays are nearly all long used to render without the split (round 2: the binary resume launch cost
+// more than the single-launch walk there).  With the four-wide resume launch the split wins on that scene too (100 k random
+// triangles, 16 spp: 29.9 ms split, 33.1 unsplit binary, 30.6 unsplit four-wide), so the hold-off is switched off; the
+// asynchronous read-back of the set-aside share stays (hpt_stats.long_rays_last_pass).
+constexpr int kSplitHold = 0;
 // device memory per path slot of one pipeline (ensure_pass): path state 80 B, pending shadow ray 48 B, five queues of 4 B
 constexpr double kBytesPerPathSlot = 148.0;
 

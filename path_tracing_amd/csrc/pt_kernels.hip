@@ -315,9 +315,23 @@ void k_connect(SceneDev sc, PathBuf pb, ShadowBuf sb, const uint32_t *squeue, co
     if(COUNT) flush_tally(tally, rays, wc, true);
 }
 
-constexpr int kLdsMats = 128;    // material records staged in LDS (6 KiB)
-constexpr int kLdsLights = 32;   // light records staged in LDS (3.5 KiB)
-constexpr int kShadeChunk = 1024;        // paths per workgroup at most (LDS staging capacity)
+#ifndef HPT_LDS_MATS
+#define HPT_LDS_MATS 128
+#endif
+#ifndef HPT_LDS_LIGHTS
+#define HPT_LDS_LIGHTS 32
+#endif
+#ifndef HPT_SHADE_CHUNK
+#define HPT_SHADE_CHUNK 1024
+#endif
+#ifdef HPT_SHADE_WAVES
+#define HPT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, 8)))
+#else
+#define HPT_SHADE_ATTR
+#endif
+constexpr int kLdsMats = HPT_LDS_MATS;    // material records staged in LDS (6 KiB)
+constexpr int kLdsLights = HPT_LDS_LIGHTS;   // light records staged in LDS (3.5 KiB)
+constexpr int kShadeChunk = HPT_SHADE_CHUNK;        // paths per workgroup at most (LDS staging capacity)
 constexpr int kShadeTargetGroups = 1024; // workgroups a short queue is spread over
 // Next-event candidates of a wave are staged in LDS and evaluated 64 at a time (see k_shade): words per record
 constexpr int kNeeWords = 20;
@@ -325,7 +339,7 @@ constexpr int kNeeWords = 20;
 // 12-14 shadow segment start | 15-17 shadow segment end | 18 path slot | 19 light index | parallel << 31
 
 template <bool PRIMARY, bool STRIDED>
-__global__ __launch_bounds__(kBlock)
+__global__ __launch_bounds__(kBlock) HPT_SHADE_ATTR
 void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qcount,
              uint32_t *next_queue, uint32_t *next_count, ShadowBuf sb, uint32_t *squeue, uint32_t *scount,
              int max_depth, int max_delta, int roulette, WorkCounters *wc, PrimaryGen pg){

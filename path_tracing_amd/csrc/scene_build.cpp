@@ -14,10 +14,21 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <array>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#ifdef __linux__
+#include <sched.h>
+#endif
 
 namespace hpt {
 namespace {
@@ -46,16 +57,106 @@ struct Box {
 
 struct Prim { Box box; float cen[3]; uint32_t index; };
 
+// Host threads for the O(n) passes of a large scene: [0, n) is cut into kChunks contiguous ranges -- always the same ones,
+// whatever the machine, so that nothing a pass derives from the cut depends on where it runs -- and the ranges are handed
+// to a small pool of helper threads (created on first use, at most kChunks - 1) and to the caller itself, which takes
+// ranges like any helper and returns when all are done: a caller never waits for a helper to START, so a pool that is
+// busy (several big subtrees at once), or gone (a forked child), only costs speed.  fn(chunk, begin, end).
+constexpr int kChunks = 32;
+constexpr size_t kParallelForMin = 65536;
+
+// Threads worth starting: the hardware's count cut down to the scheduler affinity mask, 64 at most.  (A cgroup CPU quota is
+// deliberately NOT applied: on the 16-CPU-quota GPU boxes the 1 M-triangle build measured 700 ms on 1 thread, 330-380 on
+// 16, 270-310 on 32 and 260 on 64.)
+int usable_cpus(){
+    static const int n = [](){
+        long best = (long) std::thread::hardware_concurrency();
+        if(best < 1) best = 1;
+#ifdef HPT_DEV_TUNING
+        if(const char *e = getenv("HPT_BUILD_THREADS")){ int v = atoi(e); if(v >= 1) return v; }
+#endif
+#ifdef __linux__
+        cpu_set_t set; CPU_ZERO(&set);
+        if(sched_getaffinity(0, sizeof set, &set) == 0){ long c = CPU_COUNT(&set); if(c > 0 && c < best) best = c; }
+#endif
+        return (int) std::min<long>(best, 64);
+    }();
+    return n;
+}
+
+class HelperPool {
+public:
+    static HelperPool &get(){ static HelperPool p; return p; }
+    void submit(const std::function<void()> &job, int copies){
+        { std::lock_guard<std::mutex> lock(mu_);
+          if(workers_.empty()){
+              int n = std::min(usable_cpus() - 1, kChunks - 1);
+              for(int i = 0; i < n; ++i) workers_.emplace_back([this](){ run(); });
+          }
+          for(int i = 0; i < copies && i < (int) workers_.size(); ++i) queue_.push_back(job); }
+        cv_.notify_all();
+    }
+    ~HelperPool(){
+        { std::lock_guard<std::mutex> lock(mu_); stop_ = true; }
+        cv_.notify_all();
+        for(std::thread &t : workers_) t.join();
+    }
+private:
+    void run(){
+        for(;;){
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> lock(mu_);
+              cv_.wait(lock, [this](){ return stop_ || !queue_.empty(); });
+              if(stop_) return;
+              job = std::move(queue_.front()); queue_.pop_front(); }
+            job();
+        }
+    }
+    std::mutex mu_; std::condition_variable cv_; std::deque<std::function<void()>> queue_; std::vector<std::thread> workers_; bool stop_ = false;
+};
+
+template <typename F>
+void parallel_chunks(size_t n, F fn){
+    auto range = [n](int c, size_t &b, size_t &e){ b = n * (size_t) c / kChunks; e = n * (size_t) (c + 1) / kChunks; };
+    if(n < kParallelForMin || usable_cpus() <= 1){
+        for(int c = 0; c < kChunks; ++c){ size_t b, e; range(c, b, e); if(b < e) fn(c, b, e); }
+        return;
+    }
+    struct Job { std::atomic<int> next{0}, done{0}; };
+    auto job = std::make_shared<Job>();
+    // helpers hold the job (and a copy of fn's captures by reference: valid until done == kChunks, which the caller awaits)
+    auto take = [job, range, &fn](){
+        for(;;){
+            int c = job->next.fetch_add(1);
+            if(c >= kChunks) break;
+            size_t b, e; range(c, b, e);
+            if(b < e) fn(c, b, e);
+            job->done.fetch_add(1, std::memory_order_release);
+        }
+    };
+    HelperPool::get().submit(take, kChunks - 1);
+    take();
+    while(job->done.load(std::memory_order_acquire) < kChunks) std::this_thread::yield();
+}
+
 struct Builder {
     std::vector<Prim> prims;
-    std::vector<BvhNode> nodes;
-    std::vector<uint32_t> order;      // leaf-order list of input triangle indices
+    std::vector<BvhNode> nodes;       // pre-sized by the caller; slots are handed out by next_node
+    std::atomic<uint32_t> next_node{0};
+    std::atomic<int> max_depth_seen{0};
     float pad_abs = 0.0f;
-    int max_depth_seen = 0;
     int max_leaf = kMaxLeafTris;
     uint32_t node_base = 0, tri_base = 0;     // offsets when several BVHs share one node / triangle array
 
     static constexpr int kBins = 16;
+    // Subtrees of more than kParallelMin triangles are built on their own host thread while the parent goes on with the
+    // sibling (at most as many threads at a time as the process may use CPUs).  The tree does not depend on it: a subtree over
+    // prims[first, first + count) only reads and permutes that range, its triangles keep that range of leaf slots
+    // (leaf order = the final order of prims), and node numbers -- the only thing the thread schedule decides -- are
+    // replaced by the breadth-first renumbering afterwards.
+    static constexpr int kParallelMin = 8192;
+    static int parallel_levels(){ int l = 0; while((2 << l) <= usable_cpus() && l < 6) ++l; return l; }     // 2^levels subtree threads at most
+    static constexpr size_t kBigNode = 131072;        // nodes this large bin and partition their range on several threads
 
     void write_box(float *mn, float *mx, const Box &b) const {
         // pad by an absolute slack plus two ulps so that rounding in the slab test and in
@@ -68,17 +169,41 @@ struct Builder {
         }
     }
 
-    uint32_t make_leaf(int first, int count){
-        uint32_t start = (uint32_t) order.size() + tri_base;
-        for(int i = 0; i < count; ++i) order.push_back(prims[first + i].index);
-        return kLeafFlag | (start << 3) | (uint32_t) (count - 1);
+    uint32_t make_leaf(int first, int count) const {
+        return kLeafFlag | (((uint32_t) first + tri_base) << 3) | (uint32_t) (count - 1);
+    }
+
+    // node slots are handed out in blocks of kSlotBlock per thread (one shared counter, touched once per block); the slots a
+    // thread does not use stay empty and are dropped by the breadth-first renumbering.  The root takes slot 0.
+    static constexpr uint32_t kSlotBlock = 256;
+    static constexpr size_t kSlotSlack = (size_t) kSlotBlock * 160;      // > (threads that ever build a subtree) x block: 2 x 64 spawned at most
+    const uint64_t id = [](){ static std::atomic<uint64_t> counter{0}; return ++counter; }();
+    uint32_t alloc_node(){
+        static thread_local uint64_t owner = 0;
+        static thread_local uint32_t next = 0, end = 0;
+        if(owner != id || next == end){ owner = id; next = next_node.fetch_add(kSlotBlock, std::memory_order_relaxed); end = next + kSlotBlock; }
+        return next++;
+    }
+
+    void note_depth(int depth){
+        int seen = max_depth_seen.load(std::memory_order_relaxed);
+        while(depth > seen && !max_depth_seen.compare_exchange_weak(seen, depth, std::memory_order_relaxed)){}
     }
 
     // Builds the subtree over prims[first, first+count); returns its child code and box.
-    uint32_t build(int first, int count, int depth, Box &out_box){
-        max_depth_seen = std::max(max_depth_seen, depth);
+    uint32_t build(int first, int count, int depth, Box &out_box, int par_levels = -1){
+        if(par_levels < 0) par_levels = parallel_levels();
+        note_depth(depth);
         Box bb; bb.reset();
         Box cb; cb.reset();
+        if(par_levels > 0 && (size_t) count >= kBigNode){
+            std::vector<Box> pb((size_t) kChunks), pc((size_t) kChunks);
+            for(int c = 0; c < kChunks; ++c){ pb[(size_t) c].reset(); pc[(size_t) c].reset(); }
+            parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){
+                for(size_t i = (size_t) first + b0; i < (size_t) first + e0; ++i){ pb[(size_t) c].grow(prims[i].box); pc[(size_t) c].grow(prims[i].cen); }
+            });
+            for(int c = 0; c < kChunks; ++c){ bb.grow(pb[(size_t) c]); cb.grow(pc[(size_t) c]); }
+        } else
         for(int i = first; i < first + count; ++i){ bb.grow(prims[i].box); cb.grow(prims[i].cen); }
         out_box = bb;
         if(count <= max_leaf) return make_leaf(first, count);
@@ -97,11 +222,26 @@ struct Builder {
         int mid = -1;
         if(!force_median && ext[axis] > 0.0f){
             float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+            const bool big = par_levels > 0 && (size_t) count >= kBigNode;        // the few nodes at the top of a large tree
             for(int ax = 0; ax < 3; ++ax){
                 if(!(ext[ax] > 0.0f)) continue;
                 Box bin_box[kBins]; int bin_cnt[kBins];
                 for(int b = 0; b < kBins; ++b){ bin_box[b].reset(); bin_cnt[b] = 0; }
                 float scale = (float) kBins / ext[ax];
+                if(big){
+                    // per-chunk bins merged afterwards: boxes grow by min / max and counts add, so the result is the serial one
+                    std::vector<Box> cbox((size_t) kChunks * kBins); std::vector<int> ccnt((size_t) kChunks * kBins, 0);
+                    for(Box &b : cbox) b.reset();
+                    parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){
+                        Box *bb = &cbox[(size_t) c * kBins]; int *bc = &ccnt[(size_t) c * kBins];
+                        for(size_t i = (size_t) first + b0; i < (size_t) first + e0; ++i){
+                            int b = (int) ((prims[i].cen[ax] - cb.mn[ax]) * scale);
+                            b = std::min(std::max(b, 0), kBins - 1);
+                            bb[b].grow(prims[i].box); bc[b]++;
+                        }
+                    });
+                    for(int c = 0; c < kChunks; ++c) for(int b = 0; b < kBins; ++b){ bin_box[b].grow(cbox[(size_t) c * kBins + b]); bin_cnt[b] += ccnt[(size_t) c * kBins + b]; }
+                } else
                 for(int i = first; i < first + count; ++i){
                     int b = (int) ((prims[i].cen[ax] - cb.mn[ax]) * scale);
                     b = std::min(std::max(b, 0), kBins - 1);
@@ -124,12 +264,32 @@ struct Builder {
             if(best_axis >= 0){
                 float scale = (float) kBins / ext[best_axis];
                 float lo = cb.mn[best_axis];
-                auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p){
+                auto goes_left = [&](const Prim &p){
                     int b = (int) ((p.cen[best_axis] - lo) * scale);
                     b = std::min(std::max(b, 0), kBins - 1);
                     return b <= best_bin;
-                });
-                mid = (int) (it - prims.begin());
+                };
+                if(big){
+                    // stable partition through a scratch copy: every chunk counts, then scatters to the offsets the counts give
+                    std::vector<size_t> nleft((size_t) kChunks, 0), nall((size_t) kChunks, 0);
+                    parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){
+                        size_t l = 0; for(size_t i = (size_t) first + b0; i < (size_t) first + e0; ++i) l += goes_left(prims[i]) ? 1 : 0;
+                        nleft[(size_t) c] = l; nall[(size_t) c] = e0 - b0;
+                    });
+                    size_t total_left = 0; for(size_t l : nleft) total_left += l;
+                    std::vector<size_t> loff((size_t) kChunks), roff((size_t) kChunks);
+                    { size_t l = 0, r = total_left; for(int c = 0; c < kChunks; ++c){ loff[(size_t) c] = l; roff[(size_t) c] = r; l += nleft[(size_t) c]; r += nall[(size_t) c] - nleft[(size_t) c]; } }
+                    std::vector<Prim> tmp((size_t) count);
+                    parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){
+                        size_t l = loff[(size_t) c], r = roff[(size_t) c];
+                        for(size_t i = (size_t) first + b0; i < (size_t) first + e0; ++i){ if(goes_left(prims[i])) tmp[l++] = prims[i]; else tmp[r++] = prims[i]; }
+                    });
+                    parallel_chunks((size_t) count, [&](int, size_t b0, size_t e0){ std::copy(tmp.begin() + (long) b0, tmp.begin() + (long) e0, prims.begin() + first + (long) b0); });
+                    mid = first + (int) total_left;
+                } else {
+                    auto it = std::partition(prims.begin() + first, prims.begin() + first + count, goes_left);
+                    mid = (int) (it - prims.begin());
+                }
                 if(mid == first || mid == first + count) mid = -1;
             }
         }
@@ -143,12 +303,18 @@ struct Builder {
                              });
         }
 
-        uint32_t me = (uint32_t) nodes.size();
-        nodes.emplace_back();
+        uint32_t me = alloc_node();
         // (children return codes that already include node_base / tri_base)
         Box lb, rb;
-        uint32_t lc = build(first, mid - first, depth + 1, lb);
-        uint32_t rc = build(mid, first + count - mid, depth + 1, rb);
+        uint32_t lc, rc;
+        if(par_levels > 0 && count > kParallelMin){
+            std::thread left([&](){ lc = build(first, mid - first, depth + 1, lb, par_levels - 1); });
+            rc = build(mid, first + count - mid, depth + 1, rb, par_levels - 1);
+            left.join();
+        } else {
+            lc = build(first, mid - first, depth + 1, lb, 0);
+            rc = build(mid, first + count - mid, depth + 1, rb, 0);
+        }
         BvhNode &n = nodes[me];
         write_box(n.lmin, n.lmax, lb); n.left = lc;
         write_box(n.rmin, n.rmax, rb); n.right = rc;
@@ -242,19 +408,31 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
     }
 
     auto t0 = std::chrono::steady_clock::now();
+#ifdef HPT_DEV_TUNING
+    auto tp = t0;
+    auto lap = [&](const char *what){ auto n = std::chrono::steady_clock::now(); fprintf(stderr, "  build phase %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - tp).count()); tp = n; };
+#else
+    auto lap = [](const char *){};
+#endif
     Builder B;
 #ifdef HPT_DEV_TUNING      // development builds only (`make variant EXTRA=-DHPT_DEV_TUNING`, scripts/sweep_leaf.py): the product reads no environment here
     if(const char *e = getenv("HPT_MAX_LEAF")){ int v = atoi(e); if(v >= 1 && v <= 8) B.max_leaf = v; }
 #endif
     B.prims.resize(nt);
     Box scene_box; scene_box.reset();
-    for(int i = 0; i < nt; ++i){
-        Prim &p = B.prims[i];
-        p.box.reset();
-        p.box.grow(tris[i].v0); p.box.grow(tris[i].v1); p.box.grow(tris[i].v2);
-        for(int a = 0; a < 3; ++a) p.cen[a] = 0.5f * (p.box.mn[a] + p.box.mx[a]);
-        p.index = (uint32_t) i;
-        scene_box.grow(p.box);
+    {   std::vector<Box> part((size_t) kChunks);
+        for(Box &b : part) b.reset();
+        parallel_chunks((size_t) nt, [&](int c, size_t b0, size_t e0){
+            for(size_t i = b0; i < e0; ++i){
+                Prim &p = B.prims[i];
+                p.box.reset();
+                p.box.grow(tris[i].v0); p.box.grow(tris[i].v1); p.box.grow(tris[i].v2);
+                for(int a = 0; a < 3; ++a) p.cen[a] = 0.5f * (p.box.mn[a] + p.box.mx[a]);
+                p.index = (uint32_t) i;
+                part[(size_t) c].grow(p.box);
+            }
+        });
+        for(const Box &b : part) scene_box.grow(b);
     }
     float extent = 0.0f;
     if(nt > 0) for(int a = 0; a < 3; ++a){
@@ -262,17 +440,17 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
         extent = std::max(extent, std::max(std::fabs(scene_box.mn[a]), std::fabs(scene_box.mx[a])));
     }
     B.pad_abs = 2e-6f * extent;
-    B.nodes.reserve(nt > 0 ? (size_t) nt : 1);
-    B.order.reserve(nt);
+    B.nodes.resize((nt > 0 ? (size_t) nt : 1) + Builder::kSlotSlack);          // an inner node has two non-empty subtrees: fewer than nt of them
+    lap("prims");
 
     if(nt == 0){
         BvhNode n; memset(&n, 0, sizeof n);
         set_empty_box(n.lmin, n.lmax); set_empty_box(n.rmin, n.rmax);
         n.left = n.right = kEmptyChild;
-        B.nodes.push_back(n);
+        B.nodes[0] = n; B.next_node = 1;
     } else if(nt <= B.max_leaf){
         BvhNode n; memset(&n, 0, sizeof n);
-        B.nodes.push_back(n);
+        B.nodes[0] = n; B.next_node = 1;
         Box lb;
         uint32_t lc = B.build(0, nt, 1, lb);
         B.write_box(B.nodes[0].lmin, B.nodes[0].lmax, lb); B.nodes[0].left = lc;
@@ -282,8 +460,10 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
         uint32_t root = B.build(0, nt, 0, rb);
         if(root != 0) return "internal error: BVH root is not node 0";
     }
+    lap("tree");
+    B.nodes.resize(B.next_node.load());
     hs.nodes.swap(B.nodes);
-    hs.bvh_depth = B.max_depth_seen;
+    hs.bvh_depth = B.max_depth_seen.load();
     {   // breadth-first renumbering: node 0 stays the root and every node of depth d precedes every node of depth d + 1,
         // so the nodes a ray can reach in its first k steps are the first 2^k - 1 at most (k_trace keeps those in LDS)
         const size_t n = hs.nodes.size();
@@ -295,23 +475,33 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
             for(uint32_t c : { nd.left, nd.right })
                 if(c != kEmptyChild && !(c & kLeafFlag)){ new_index[c] = (uint32_t) order.size(); order.push_back(c); }
         }
-        if(order.size() != n) return "internal error: BVH nodes unreachable from the root";
-        std::vector<BvhNode> sorted(n);
-        for(size_t i = 0; i < n; ++i){
-            BvhNode nd = hs.nodes[order[i]];
-            if(nd.left != kEmptyChild && !(nd.left & kLeafFlag)) nd.left = new_index[nd.left];
-            if(nd.right != kEmptyChild && !(nd.right & kLeafFlag)) nd.right = new_index[nd.right];
-            sorted[i] = nd;
-        }
+        // (slots a build thread reserved and did not use are not reachable and drop out here)
+        const size_t reachable = order.size();
+        std::vector<BvhNode> sorted(reachable);
+        parallel_chunks(reachable, [&](int, size_t b0, size_t e0){
+            for(size_t i = b0; i < e0; ++i){
+                BvhNode nd = hs.nodes[order[i]];
+                if(nd.left != kEmptyChild && !(nd.left & kLeafFlag)) nd.left = new_index[nd.left];
+                if(nd.right != kEmptyChild && !(nd.right & kLeafFlag)) nd.right = new_index[nd.right];
+                sorted[i] = nd;
+            }
+        });
         hs.nodes.swap(sorted);
     }
+    lap("renumber");
     {   // quantised twin: 16-bit grid over the union of the (padded) node boxes
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for(const BvhNode &n : hs.nodes){
-            for(int a = 0; a < 3; ++a){
-                if(n.left != kEmptyChild){ lo[a] = std::min(lo[a], n.lmin[a]); hi[a] = std::max(hi[a], n.lmax[a]); }
-                if(n.right != kEmptyChild){ lo[a] = std::min(lo[a], n.rmin[a]); hi[a] = std::max(hi[a], n.rmax[a]); }
-            }
+        {   std::vector<Box> part((size_t) kChunks);
+            for(Box &b : part) b.reset();
+            parallel_chunks(hs.nodes.size(), [&](int c, size_t b0, size_t e0){
+                Box &pb = part[(size_t) c];
+                for(size_t i = b0; i < e0; ++i){
+                    const BvhNode &n = hs.nodes[i];
+                    if(n.left != kEmptyChild){ pb.grow(n.lmin); pb.grow(n.lmax); }
+                    if(n.right != kEmptyChild){ pb.grow(n.rmin); pb.grow(n.rmax); }
+                }
+            });
+            for(const Box &b : part) for(int a = 0; a < 3; ++a){ lo[a] = std::min(lo[a], b.mn[a]); hi[a] = std::max(hi[a], b.mx[a]); }
         }
         for(int a = 0; a < 3; ++a){
             if(!(lo[a] <= hi[a])){ lo[a] = 0.0f; hi[a] = 1.0f; }
@@ -323,73 +513,99 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
         auto qlo = [&](float v, int a){ double q = std::floor(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) - 1.0; return (uint16_t) std::min(65535.0, std::max(0.0, q)); };
         auto qhi = [&](float v, int a){ double q = std::ceil(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) + 1.0; return (uint16_t) std::min(65535.0, std::max(0.0, q)); };
         hs.qnodes.resize(hs.nodes.size());
-        for(size_t i = 0; i < hs.nodes.size(); ++i){
-            const BvhNode &n = hs.nodes[i]; QBvhNode &q = hs.qnodes[i];
-            for(int a = 0; a < 3; ++a){
-                if(n.left != kEmptyChild){ q.lmin[a] = qlo(n.lmin[a], a); q.lmax[a] = qhi(n.lmax[a], a); } else { q.lmin[a] = 65535; q.lmax[a] = 0; }
-                if(n.right != kEmptyChild){ q.rmin[a] = qlo(n.rmin[a], a); q.rmax[a] = qhi(n.rmax[a], a); } else { q.rmin[a] = 65535; q.rmax[a] = 0; }
+        parallel_chunks(hs.nodes.size(), [&](int, size_t b0, size_t e0){
+            for(size_t i = b0; i < e0; ++i){
+                const BvhNode &n = hs.nodes[i]; QBvhNode &q = hs.qnodes[i];
+                for(int a = 0; a < 3; ++a){
+                    if(n.left != kEmptyChild){ q.lmin[a] = qlo(n.lmin[a], a); q.lmax[a] = qhi(n.lmax[a], a); } else { q.lmin[a] = 65535; q.lmax[a] = 0; }
+                    if(n.right != kEmptyChild){ q.rmin[a] = qlo(n.rmin[a], a); q.rmax[a] = qhi(n.rmax[a], a); } else { q.rmin[a] = 65535; q.rmax[a] = 0; }
+                }
+                q.left = n.left; q.right = n.right;
             }
-            q.left = n.left; q.right = n.right;
-        }
+        });
     }
     if(hs.bvh_depth > kMaxBvhDepth) return "internal error: BVH deeper than the traversal stack";
+    lap("quantise");
     {   // four-wide twin: greedy collapse of the binary tree, breadth-first numbering, same quantised child boxes
         struct Kid { const float *mn, *mx; uint32_t code; };
         auto half_area = [](const Kid &k){ float dx = k.mx[0] - k.mn[0], dy = k.mx[1] - k.mn[1], dz = k.mx[2] - k.mn[2]; return dx * dy + dy * dz + dz * dx; };
         auto qlo = [&](float v, int a){ double q = std::floor(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) - 1.0; return (uint32_t) std::min(65535.0, std::max(0.0, q)); };
         auto qhi = [&](float v, int a){ double q = std::ceil(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) + 1.0; return (uint32_t) std::min(65535.0, std::max(0.0, q)); };
+        struct Kids { Kid k[4]; int n; uint32_t code[4]; };
         std::vector<uint32_t> todo{0u};            // binary node each wide node was collapsed from
         std::vector<int> depth{1};
-        hs.wnodes.clear(); hs.wnodes.emplace_back();
+        std::vector<Kids> all; all.reserve(hs.nodes.size() / 2 + 1);
+        // pass 1 (serial, breadth-first): which child boxes a wide node holds and the numbers of its inner children
         for(size_t qi = 0; qi < todo.size(); ++qi){
-            Kid kids[4]; int nk = 0;
+            Kids ks; ks.n = 0;
             auto open = [&](uint32_t idx){
                 const BvhNode &b = hs.nodes[idx];
-                if(b.left != kEmptyChild) kids[nk++] = Kid{ b.lmin, b.lmax, b.left };
-                if(b.right != kEmptyChild) kids[nk++] = Kid{ b.rmin, b.rmax, b.right };
+                if(b.left != kEmptyChild) ks.k[ks.n++] = Kid{ b.lmin, b.lmax, b.left };
+                if(b.right != kEmptyChild) ks.k[ks.n++] = Kid{ b.rmin, b.rmax, b.right };
             };
             open(todo[qi]);
-            while(nk < 4){
+            while(ks.n < 4){
                 int best = -1; float ba = -1.0f;
-                for(int k = 0; k < nk; ++k) if(!(kids[k].code & kLeafFlag)){ float a = half_area(kids[k]); if(a > ba){ ba = a; best = k; } }
+                for(int k = 0; k < ks.n; ++k) if(!(ks.k[k].code & kLeafFlag)){ float a = half_area(ks.k[k]); if(a > ba){ ba = a; best = k; } }
                 if(best < 0) break;
-                // an inner binary node has two children at most: opening one replaces it by them (nk grows by one at most)
-                uint32_t c = kids[best].code;
-                kids[best] = kids[nk - 1]; --nk;
+                // an inner binary node has two children at most: opening one replaces it by them (n grows by one at most)
+                uint32_t c = ks.k[best].code;
+                ks.k[best] = ks.k[ks.n - 1]; --ks.n;
                 open(c);
             }
-            WideNode w;
-            uint32_t lo[3][4], hi[3][4], code[4];
             for(int k = 0; k < 4; ++k){
-                if(k < nk){
-                    for(int a = 0; a < 3; ++a){ lo[a][k] = qlo(kids[k].mn[a], a); hi[a][k] = qhi(kids[k].mx[a], a); }
-                    if(kids[k].code & kLeafFlag) code[k] = kids[k].code;
-                    else { code[k] = (uint32_t) todo.size(); todo.push_back(kids[k].code); depth.push_back(depth[qi] + 1); hs.wnodes.emplace_back(); }
-                } else { for(int a = 0; a < 3; ++a){ lo[a][k] = 65535u; hi[a][k] = 0u; } code[k] = kEmptyChild; }
+                if(k >= ks.n) ks.code[k] = kEmptyChild;
+                else if(ks.k[k].code & kLeafFlag) ks.code[k] = ks.k[k].code;
+                else { ks.code[k] = (uint32_t) todo.size(); todo.push_back(ks.k[k].code); depth.push_back(depth[qi] + 1); }
             }
-            for(int a = 0; a < 3; ++a){
-                w.w[a * 4 + 0] = lo[a][0] | (lo[a][1] << 16); w.w[a * 4 + 1] = lo[a][2] | (lo[a][3] << 16);
-                w.w[a * 4 + 2] = hi[a][0] | (hi[a][1] << 16); w.w[a * 4 + 3] = hi[a][2] | (hi[a][3] << 16);
-            }
-            for(int k = 0; k < 4; ++k) w.w[12 + k] = code[k];
-            hs.wnodes[qi] = w;
+            all.push_back(ks);
             hs.wide_depth = std::max(hs.wide_depth, depth[qi]);
         }
+        // pass 2: quantise and pack
+        hs.wnodes.assign(all.size(), WideNode{});
+        parallel_chunks(all.size(), [&](int, size_t b0, size_t e0){
+            for(size_t qi = b0; qi < e0; ++qi){
+                const Kids &ks = all[qi];
+                WideNode w;
+                uint32_t lo[3][4], hi[3][4];
+                for(int k = 0; k < 4; ++k){
+                    if(k < ks.n){ for(int a = 0; a < 3; ++a){ lo[a][k] = qlo(ks.k[k].mn[a], a); hi[a][k] = qhi(ks.k[k].mx[a], a); } }
+                    else { for(int a = 0; a < 3; ++a){ lo[a][k] = 65535u; hi[a][k] = 0u; } }
+                }
+                for(int a = 0; a < 3; ++a){
+                    w.w[a * 4 + 0] = lo[a][0] | (lo[a][1] << 16); w.w[a * 4 + 1] = lo[a][2] | (lo[a][3] << 16);
+                    w.w[a * 4 + 2] = hi[a][0] | (hi[a][1] << 16); w.w[a * 4 + 3] = hi[a][2] | (hi[a][3] << 16);
+                }
+                for(int k = 0; k < 4; ++k) w.w[12 + k] = ks.code[k];
+                hs.wnodes[qi] = w;
+            }
+        });
     }
 
+    lap("wide");
     hs.tris.resize(nt);
-    for(int s = 0; s < nt; ++s){
-        const RefTriangle &t = tris[B.order[s]];
-        DevTriangle &d = hs.tris[s];
-        for(int a = 0; a < 3; ++a){
-            d.v0[a] = t.v0[a];
-            d.e1[a] = t.v1[a] - t.v0[a];          // geometric.cuh:266-267
-            d.e2[a] = t.v2[a] - t.v0[a];
+    {   // materials are numbered in order of first appearance (leaf order): one serial pass that mostly hits its one-entry cache
+        RefMat last; memset(&last, 0xFF, sizeof last); uint32_t last_idx = 0; bool have = false;
+        for(int s = 0; s < nt; ++s){
+            const RefMat &m = tris[B.prims[s].index].m;
+            if(!have || memcmp(&m, &last, 28) != 0){ last_idx = intern_material(m, mat_table, hs.materials); last = m; have = true; }
+            hs.tris[s].material = last_idx;
         }
-        d.ordinal = (uint32_t) (ns + nl) + B.order[s];
-        d.material = intern_material(t.m, mat_table, hs.materials);
-        d.flags = (t.m.eta <= 0.0f) ? 1u : 0u;
     }
+    parallel_chunks((size_t) nt, [&](int, size_t b0, size_t e0){
+        for(size_t s = b0; s < e0; ++s){
+            const RefTriangle &t = tris[B.prims[s].index];        // leaf order = the order the build left the primitives in
+            DevTriangle &d = hs.tris[s];
+            for(int a = 0; a < 3; ++a){
+                d.v0[a] = t.v0[a];
+                d.e1[a] = t.v1[a] - t.v0[a];          // geometric.cuh:266-267
+                d.e2[a] = t.v2[a] - t.v0[a];
+            }
+            d.ordinal = (uint32_t) (ns + nl) + B.prims[s].index;
+            d.flags = (t.m.eta <= 0.0f) ? 1u : 0u;
+        }
+    });
+    lap("triangles");
     auto t1 = std::chrono::steady_clock::now();
     hs.ms_bvh_build = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if(hs.materials.empty()){ DevMaterial m; memset(&m, 0, sizeof m); hs.materials.push_back(m); }
@@ -486,13 +702,14 @@ const char *build_bdpt_host_scene(const void *lights_v, int nl, const void *sphe
             for(int a = 0; a < 3; ++a) p.cen[a] = 0.5f * (p.box.mn[a] + p.box.mx[a]);
             p.index = (uint32_t) i;
         }
+        B.nodes.resize(std::max<size_t>(gtris.size(), 1) + Builder::kSlotSlack);
         if(gtris.empty()) g.root = kEmptyChild;
         else { Box rb; g.root = B.build(0, (int) gtris.size(), 0, rb); }
-        if(B.max_depth_seen > kMaxBvhDepth) return "internal error: BVH deeper than the traversal stack";
-        out.bvh_depth = std::max(out.bvh_depth, B.max_depth_seen);
-        out.nodes.insert(out.nodes.end(), B.nodes.begin(), B.nodes.end());
-        for(uint32_t oi : B.order){
-            const Item &it = gtris[oi];
+        if(B.max_depth_seen.load() > kMaxBvhDepth) return "internal error: BVH deeper than the traversal stack";
+        out.bvh_depth = std::max(out.bvh_depth, B.max_depth_seen.load());
+        out.nodes.insert(out.nodes.end(), B.nodes.begin(), B.nodes.begin() + B.next_node.load());
+        for(const Prim &pr : B.prims){
+            const Item &it = gtris[pr.index];
             const RefTriangle &t = tris[it.index];
             DevTriangle d;
             for(int a = 0; a < 3; ++a){ d.v0[a] = t.v0[a]; d.e1[a] = t.v1[a] - t.v0[a]; d.e2[a] = t.v2[a] - t.v0[a]; }   // src/object.cpp:75
