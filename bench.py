@@ -99,6 +99,61 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def fanout_main(args):
+    """`--fanout`: the same workload through hpt_multi_render_pt -- ONE process, one host thread per device, image tiles per
+    device, ncclGather on the first device, host image out (what SURVEY 8(b) calls "multi-GPU fan-out is internal").  The
+    timed region is the blocking call itself, so unlike the default mode it includes the copy of the image to host memory
+    (12 MB at 1024^2); `value` stays whole-job samples per second."""
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    import path_tracing_amd as hpt
+    from path_tracing_amd import scene_io
+    ndev = hpt.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    n = args.gpus
+    if n > ndev and args.fanout_exchange != 1:
+        raise SystemExit("bench.py --fanout --gpus %d: %d device(s) visible (--fanout-exchange 1 lets ranks share a device)" % (n, ndev))
+    ids = [i % ndev for i in range(n)]
+    W = H = args.size
+    lights, spheres, tris = scene_io.cornell_with_sphere(args.tris)
+    cam = scene_io.make_camera(scene_io.CORNELL_EYE, scene_io.CORNELL_LOOK, scene_io.CORNELL_UP, 50.0, W, H)
+    per_rank, gathers, totals = [], [], []
+    with hpt.MultiScene(lights, spheres, tris, device_ids=ids, exchange=args.fanout_exchange) as ms:
+        p = hpt.make_params(seed=1, flags=hpt.FLAG_SINGLE_PIPELINE if args.single_pipeline else 0)
+        first = None
+        for i in range(args.warmup):
+            img = ms.render_pt(cam, W, H, args.depth, args.spp, p)
+            if first is None:
+                first = img
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img = ms.render_pt(cam, W, H, args.depth, args.spp, p)
+            t = ms.timing()
+            per_rank.append(t["render_ms_per_device"]); gathers.append(t["gather_ms"]); totals.append(t["total_ms"])
+        dt = time.perf_counter() - t0
+    pr = np.array(per_rank)
+    out = {"metric": "Msamples/s (paths/s) at 1024^2 x 256spp", "value": W * H * args.spp * args.steps / dt / 1e6, "unit": "Msamples/s",
+           "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[2]: unidirectional PT + NEE, Cornell-style box + tessellated sphere, %d triangles behind a BVH, %dx%d, "
+                                  "%d spp, depth %d, 1 cone light" % (len(tris), W, H, args.spp, args.depth),
+                      "parallelism": "ONE process, hpt_multi_render_pt: image tiles 32x32 round-robin over %d device rank(s) %s, %s to the first device, "
+                                     "host image out" % (n, ids, "ncclGather (RCCL)" if args.fanout_exchange == 0 else "peer copies"), "seed": 1},
+           "fanout": {"render_ms_per_rank_mean_over_steps": pr.mean(axis=0).tolist(), "render_ms_max_rank": float(pr.max(axis=1).mean()),
+                      "render_ms_mean_rank": float(pr.mean()), "load_balance_max_over_mean": float((pr.max(axis=1) / pr.mean(axis=1)).mean()),
+                      "gather_ms_per_step": gathers, "call_ms_per_step": totals,
+                      "note": "device time of every rank's render (HIP events), of the exchange step, and host wall time of each blocking call; "
+                              "the timed region includes the image copy to host memory"},
+           "verify": {"image_finite_and_lit": bool(np.isfinite(img).all() and img.mean() > 0),
+                      "timed_image_equals_first_warmup_image": bool(first is None or np.array_equal(img, first))}}
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
+    if not all(out["verify"].values()):
+        raise SystemExit("bench.py --fanout: verification failed: %s" % out["verify"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,9 +168,16 @@ def main():
     ap.add_argument("--no-exclusive-step", action="store_true", help="skip the extra untimed single-pipeline step that measures the kernels' exclusive durations")
     ap.add_argument("--no-count-step", action="store_true", help="skip the untimed work-counting render (profiling runs: the timed kernels only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path on a one-GPU box)")
-    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
+    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))
+    ap.add_argument("--fanout", action="store_true",
+                    help="time the boundary's own one-process fan-out (hpt_multi_render_pt: one host thread per device, RCCL gather behind the "
+                         "blocking call) over --gpus devices instead of one process per GPU")
+    ap.add_argument("--fanout-exchange", type=int, default=0, help="--fanout: 0 = RCCL gather (distinct devices), 1 = peer copies "
+                                                                   "(also lets several ranks share one device: a rehearsal on a one-GPU box)")
     args = ap.parse_args()
 
+    if args.fanout:
+        return fanout_main(args)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))        # nothing has touched the GPU yet
 
@@ -202,9 +264,11 @@ def main():
     fence()
     t0 = time.perf_counter()
     ext_ms, ext_n, tot_ms, res_ms, res_n, shd_ms, shd_n = 0.0, 0, 0.0, 0.0, 0, 0.0, 0
+    step_render_ms = []                    # this rank's device time per step (HIP events first-to-last kernel)
     for _ in range(args.steps):
         step(base_flags | hpt.FLAG_TIME_KERNELS, timed_gather=True)        # HIP events around every launch, on the launch stream
         st = scene.stats()                 # waits for this rank's render
+        step_render_ms.append(st["ms_total"])
         ext_ms += st["ms_extend"] + st["ms_connect"]; ext_n += st["n_extend"] + st["n_connect"]; tot_ms += st["ms_total"]
         res_ms += st["ms_resume"]; res_n += st["n_resume"]; shd_ms += st["ms_shade"]; shd_n += st["n_shade"]
         shade_ms, connect_ms, other_ms = st["ms_shade"], st["ms_connect"], st["ms_other"]
@@ -215,6 +279,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     gather_ms = [gather_events[i].elapsed_time(gather_events[i + 1]) for i in range(0, len(gather_events) - 1, 2)]
+    # every rank's render time of every step, collected after the timed region (not on the critical path)
+    rank_ms = None
+    if world > 1:
+        mine = torch.tensor(step_render_ms, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        rank_ms = np.array([t.cpu().numpy() for t in everyone])          # [rank][step]
     timed_image = image.clone() if rank == 0 else None
 
     # ---- untimed: checks of what was just timed + the kernels' exclusive durations + the work counts ----
@@ -257,10 +328,18 @@ def main():
             "exchange": {"backend": dist.get_backend() if dist.is_initialized() else None,
                          "ranks_in_communicator": dist.get_world_size() if dist.is_initialized() else 0,
                          "gather_ms_per_step_rank0": float(np.mean(gather_ms)) if gather_ms else None,
+                         "gather_ms_every_step_rank0": [float(x) for x in gather_ms],
                          "gather_bytes_per_rank": int(n_local) * 12, "error": comm_error,
                          "note": "dist.gather of the packed local framebuffers to rank 0 (every step, inside the timed region; at 1 rank it "
                                  "still goes through the communicator), HIP events on the render stream around the call"},
         }
+        if rank_ms is not None:
+            out["ranks"] = {"render_ms_per_rank_mean_over_steps": rank_ms.mean(axis=1).tolist(),
+                            "render_ms_max_rank": float(rank_ms.max(axis=0).mean()), "render_ms_mean_rank": float(rank_ms.mean()),
+                            "load_balance_max_over_mean": float((rank_ms.max(axis=0) / rank_ms.mean(axis=0)).mean()),
+                            "render_ms_every_step": rank_ms.tolist(),
+                            "note": "device time of each rank's render per step (HIP events, first to last kernel); the step's wall time is the "
+                                    "slowest rank + the gather + the untile on rank 0"}
         if wc is not None:
             # dominant kernel: k_trace (closest-hit + any-hit BVH traversal).  One trace step per iteration = the first
             # launch (every ray, `split_budget` node steps) + the resume launch (the rays that need more); "launch" below
@@ -369,6 +448,19 @@ def main():
             verify["oracle_window"] = {"window": list(WINDOW), "spp": ref_spp, "rmse": float(np.sqrt((d * d).mean())),
                                        "max_abs": float(np.abs(d).max()), "bit_identical": bool(np.array_equal(got, ref_win)),
                                        "oracle": "oracle/pt_oracle.cpp (brute-force scans), the pt_port render timed above"}
+            # the roofline's numerator, checked: device work counts of a small counting render of this scene == the oracle's host walk of
+            # the tree the device holds ("counted by the build's deterministic CPU restatement traversing the same BVH")
+            import oracle
+            cw = 256
+            cam_small = scene_io.make_camera(scene_io.CORNELL_EYE, scene_io.CORNELL_LOOK, scene_io.CORNELL_UP, 50.0, cw, cw)
+            small = scene.render_pt(cam_small, cw, cw, args.depth, 2, hpt.make_params(seed=1, flags=hpt.FLAG_COUNT_WORK))
+            dev_counts = scene.stats()
+            ref_small, host_counts = oracle.pt_render(lights, spheres, tris, cam_small, cw, cw, args.depth, 2, seed=1, bvh=scene.export_bvh())
+            keys = ("closest_rays", "shadow_rays", "boxes_closest", "tris_closest", "boxes_shadow", "tris_shadow")
+            verify["work_counts_equal_host_walk"] = {"render": "%dx%d x 2 spp of the bench scene" % (cw, cw),
+                                                     "device": {k: int(dev_counts[k]) for k in keys}, "host_walk": {k: int(host_counts[k]) for k in keys},
+                                                     "equal": all(int(dev_counts[k]) == int(host_counts[k]) for k in keys),
+                                                     "images_bit_identical": bool(np.array_equal(small, ref_small))}
         out["verify"] = verify
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
@@ -377,6 +469,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     bad = [k for k, v in verify.items() if v is False] if rank == 0 else []
+    if rank == 0 and "work_counts_equal_host_walk" in verify and not (verify["work_counts_equal_host_walk"]["equal"] and verify["work_counts_equal_host_walk"]["images_bit_identical"]):
+        bad.append("work_counts_equal_host_walk")
     if rank == 0 and (bad or ("oracle_window" in verify and not verify["oracle_window"]["rmse"] < 1e-3)):
         raise SystemExit("bench.py: verification failed: %s" % (bad or verify["oracle_window"]))
 

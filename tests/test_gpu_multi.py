@@ -218,3 +218,29 @@ def test_bench_self_spawned_ranks_share_the_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["exchange"]["ranks_in_communicator"] == 2 and out["exchange"]["backend"] == "gloo"
     assert out["value"] > 0 and all(v is True for v in out["verify"].values()), out["verify"]
+    # N > 1: every rank's render time of every step and the gather time of every step are in the line
+    r = out["ranks"]
+    assert len(r["render_ms_per_rank_mean_over_steps"]) == 2 and len(r["render_ms_every_step"]) == 2 and len(r["render_ms_every_step"][0]) == 1
+    assert r["render_ms_max_rank"] >= r["render_ms_mean_rank"] > 0 and r["load_balance_max_over_mean"] >= 1.0
+    assert len(out["exchange"]["gather_ms_every_step_rank0"]) == 1
+
+
+def test_bench_fanout_mode_times_the_one_process_fan_out():
+    """`python bench.py --fanout --gpus N`: the same workload through hpt_multi_render_pt (one process, one host thread
+    per device, gather behind the blocking call).  On the one-GPU box: N = 1 over RCCL, and 3 ranks sharing the device
+    with peer copies; one JSON line each, per-rank render times and the gather time of every step included."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, n in ((["--gpus", "1"], 1), (["--gpus", "3", "--fanout-exchange", "1"], 3)):
+        run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--fanout", "--size", "256", "--spp", "16", "--tris", "5000",
+                              "--steps", "2", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        lines = [l for l in run.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, run.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == n and out["value"] > 0 and all(out["verify"].values())
+        f = out["fanout"]
+        assert len(f["render_ms_per_rank_mean_over_steps"]) == n and len(f["gather_ms_per_step"]) == 2 and len(f["call_ms_per_step"]) == 2
+        assert f["load_balance_max_over_mean"] >= 1.0

@@ -109,3 +109,21 @@ def test_bench_starts_its_own_ranks_as_a_child_process(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and os.path.basename(cmd[-5]) == "bench.py"
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_gather_bytes_cover_the_tiled_image(hpt, G):
+    """What N ranks send to the root in one step: `exchange.gather_bytes_per_rank` (12 B per packed local framebuffer
+    slot) x N == 12 B x the pixels of the image rounded up to whole 32 x 32 tiles and to an equal number of tiles per
+    rank -- at config 5's 4096^2 and at a size that is not a multiple of the tile."""
+    for W, H in ((4096, 4096), (1000, 700)):
+        tile = 32
+        tiles = ((W + tile - 1) // tile) * ((H + tile - 1) // tile)
+        per_rank_tiles = (tiles + G - 1) // G
+        n_local = [hpt.local_pixels(W, H, hpt.make_params(rank=r, world=G)) for r in range(G)]
+        assert len(set(n_local)) == 1                                     # every rank's buffer has the same size: one fixed-size gather
+        gather_bytes_per_rank = n_local[0] * 12
+        assert gather_bytes_per_rank * G == 12 * per_rank_tiles * G * tile * tile
+        assert gather_bytes_per_rank * G >= 12 * W * H
+        if W % tile == 0 and H % tile == 0 and tiles % G == 0:
+            assert gather_bytes_per_rank * G == 12 * W * H                # config 5: 201 326 592 B in all, 25 165 824 B per rank at G = 8
