@@ -110,6 +110,11 @@ typedef struct hpt_stats {
     double ms_resume;                 /* resume launches; TIME_KERNELS only (ms_extend / ms_connect then hold the first launches) */
     uint32_t n_resume, split_budget;  /* split_budget 0: single-launch trace steps */
     uint64_t traced_rays_last_pass, long_rays_last_pass;   /* rays entering the trace steps of the last pass / set aside for resume */
+    /* connection stage of a bidirectional render (COUNT_WORK only; reference loop src/cpu_bdpt.cpp:387-440): candidate (eye vertex,
+     * light vertex) pairs, pairs that pass the culls (zero throughput, distance, cosines, emission cone), shadow rays traced (both
+     * BSDF values non-zero), unoccluded ones; and the work of those shadow rays: BVH nodes visited (64 B each), triangle, sphere
+     * and group-box tests */
+    uint64_t bd_pairs, bd_survivors, bd_shadow_rays, bd_unoccluded, bd_nodes, bd_tris, bd_spheres, bd_group_boxes;
 } hpt_stats;
 
 const char *hpt_last_error(void);

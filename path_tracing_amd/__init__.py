@@ -55,7 +55,9 @@ class Stats(C.Structure):
                 ("leaf_lane_closest", C.c_uint64), ("leaf_wave_closest", C.c_uint64),
                 ("leaf_lane_shadow", C.c_uint64), ("leaf_wave_shadow", C.c_uint64),
                 ("ms_resume", C.c_double), ("n_resume", C.c_uint32), ("split_budget", C.c_uint32),
-                ("traced_rays_last_pass", C.c_uint64), ("long_rays_last_pass", C.c_uint64)]
+                ("traced_rays_last_pass", C.c_uint64), ("long_rays_last_pass", C.c_uint64),
+                ("bd_pairs", C.c_uint64), ("bd_survivors", C.c_uint64), ("bd_shadow_rays", C.c_uint64), ("bd_unoccluded", C.c_uint64),
+                ("bd_nodes", C.c_uint64), ("bd_tris", C.c_uint64), ("bd_spheres", C.c_uint64), ("bd_group_boxes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -72,7 +72,7 @@ void launch_bdpt_vertex(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptP
                         uint32_t *cqueue, uint32_t *ccount, int eye_depth, int max_delta, uint32_t slots, const float eye[3]);
 void launch_bdpt_connect(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lv,
                          const LightVertexCtx *lctx, int n_lv, int light_depth, const uint32_t *cqueue, const uint32_t *ccount,
-                         uint32_t max_items, uint32_t slots, uint32_t max_groups = 0);
+                         uint32_t max_items, uint32_t slots, uint32_t max_groups = 0, WorkCounters *wc = nullptr);
 void launch_bdpt_reduce(hipStream_t s, PathBuf pb, BdptPathBuf bp, int n_lv, const uint32_t *cqueue, const uint32_t *ccount,
                         uint32_t max_items, uint32_t max_groups = 0);
 

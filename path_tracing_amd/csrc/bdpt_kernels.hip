@@ -113,9 +113,12 @@ HPT_DEV bool cpu_triangle(f3 v0, f3 e1, f3 e2, f3 O, f3 vec, float tMin, float t
 
 // Walks one group's BVH.  Closest: candidates with t <= best_t, ties to the HIGHER iteration order
 // (the CPU loop accepts t <= best.t in insertion order).  ANY: true at the first opaque hit.
-template <bool ANY>
+// work of the connection shadow rays of one lane (HPT_FLAG_COUNT_WORK renders of the bidirectional path)
+struct BdTally { uint32_t nodes, tris, spheres, group_boxes; };
+
+template <bool ANY, bool COUNT = false>
 HPT_DEV bool bd_walk(const BdptSceneDev &sc, uint32_t root, f3 ro, f3 rd, float tMin, float tmax, uint32_t *stk,
-                     float &best_t, uint32_t &best_code, uint32_t &best_seq){
+                     float &best_t, uint32_t &best_code, uint32_t &best_seq, BdTally *tally = nullptr){
     if(root == kEmptyChild) return false;
     float dx = fabsf(rd.x) > 1e-20f ? rd.x : copysignf(1e-20f, rd.x);
     float dy = fabsf(rd.y) > 1e-20f ? rd.y : copysignf(1e-20f, rd.y);
@@ -130,6 +133,7 @@ HPT_DEV bool bd_walk(const BdptSceneDev &sc, uint32_t root, f3 ro, f3 rd, float 
         if(!(cur & kLeafFlag)){
             const float4 *n = sc.nodes + (size_t) cur * 4;
             float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if(COUNT) tally->nodes += 1u;
             float a0 = fmaf(n0.x, ix, -ox), a1 = fmaf(n1.x, ix, -ox);
             float b0 = fmaf(n0.y, iy, -oy), b1 = fmaf(n1.y, iy, -oy);
             float c0 = fmaf(n0.z, iz, -oz), c1 = fmaf(n1.z, iz, -oz);
@@ -158,6 +162,7 @@ HPT_DEV bool bd_walk(const BdptSceneDev &sc, uint32_t root, f3 ro, f3 rd, float 
                 const float4 *tp = sc.tris + (size_t) (first + k) * 3;
                 float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                 float t;
+                if(COUNT) tally->tris += 1u;
                 if(cpu_triangle(xyz(t0), xyz(t1), xyz(t2), ro, rd, tMin, ANY ? tmax : best_t, t)){
                     if(ANY){
                         if(f2u(t2.w) & 1u) return true;
@@ -205,21 +210,24 @@ HPT_DEV void bd_closest(const BdptSceneDev &sc, f3 ro, f3 rd, uint32_t *stk, flo
 }
 
 // cpu_check_visibility, src/cpu_bdpt.cpp:82-107
-HPT_DEV bool bd_visible(const BdptSceneDev &sc, f3 p1, f3 p2, uint32_t *stk){
+template <bool COUNT = false>
+HPT_DEV bool bd_visible(const BdptSceneDev &sc, f3 p1, f3 p2, uint32_t *stk, BdTally *tally = nullptr){
     f3 diff = p2 - p1;
     float dist = length3(diff);
     f3 dir = diff / dist;
     float max_dist = dist - 1e-3f;
     for(int gi = 0; gi < sc.num_groups; ++gi){
         DevGroup g = sc.groups[gi];
+        if(COUNT) tally->group_boxes += 1u;
         if(!group_box_hit(g, p1, dir, 1e-3f, max_dist)) continue;
         for(uint32_t k = 0; k < g.sphere_count; ++k){
             DevRound s = sc.spheres[g.sphere_first + k];
             float t;
+            if(COUNT) tally->spheres += 1u;
             if(cpu_sphere(mk3(s.c[0], s.c[1], s.c[2]), s.r, p1, dir, 1e-3f, max_dist, t) && (s.flags & 1u)) return false;
         }
         float bt = max_dist; uint32_t code = 0, seq = 0;
-        if(bd_walk<true>(sc, g.root, p1, dir, 1e-3f, max_dist, stk, bt, code, seq)) return false;
+        if(bd_walk<true, COUNT>(sc, g.root, p1, dir, 1e-3f, max_dist, stk, bt, code, seq, tally)) return false;
     }
     return true;
 }
@@ -657,9 +665,12 @@ HPT_DEV float bd_mis_weight(const BdptPathBuf &bp, uint32_t path, uint32_t slots
 // workgroup of pairs (and once at the end), so every wave of phase 2 has all its lanes busy whatever fraction of
 // the candidates survives.  The table is indexed by (vertex, light vertex), so the order of evaluation is free.
 // Frames, local directions, Lambda terms and diffuse lobes come from the per-vertex contexts.
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock)
 void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lvs, const LightVertexCtx *lctx, int n_lv,
-                    int light_depth, const uint32_t *cqueue, const uint32_t *ccount, uint32_t slots){
+                    int light_depth, const uint32_t *cqueue, const uint32_t *ccount, uint32_t slots, WorkCounters *wc){
+    BdTally tally; tally.nodes = tally.tris = tally.spheres = tally.group_boxes = 0u;
+    uint32_t n_pairs = 0u, n_survivors = 0u, n_shadow = 0u, n_lit = 0u;
     extern __shared__ uint32_t s_dyn_stack[];          // [stack level][lane], sized by the scene's deepest group tree
     __shared__ uint32_t s_pair_path[2 * kBlock];
     __shared__ uint32_t s_pair_j[2 * kBlock];
@@ -698,7 +709,9 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
             bsdf_eval_pdf<true, false>(lv_mat(lv), cl, wi * -1.0f, fL, pdf_unused, &pl);
         }
         bool ok = !((fE.x <= 0.0f && fE.y <= 0.0f && fE.z <= 0.0f) || (fL.x <= 0.0f && fL.y <= 0.0f && fL.z <= 0.0f));
-        if(ok && bd_visible(sc, v_pos + v_n * kEps, ld3(lv.pos) + ld3(lv.normal) * kEps, stk)){
+        if(COUNT){ n_survivors += 1u; if(ok) n_shadow += 1u; }
+        if(ok && bd_visible<COUNT>(sc, v_pos + v_n * kEps, ld3(lv.pos) + ld3(lv.normal) * kEps, stk, &tally)){
+            if(COUNT) n_lit += 1u;
             float G = (cosE * cosL) / fmaxf(dist2, 1e-4f);
             const size_t first = (size_t) (j / light_depth) * light_depth;
             float mis_w = bd_mis_weight(bp, path, slots, depth, vm, lvs + first, lcp, t_idx, d_vec, dist2);
@@ -717,6 +730,7 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
         if(w < items){
             path = cqueue[(uint32_t) (w / chunks)];
             j = (int) ((uint32_t) (w % chunks) * 64u + lane);
+            if(COUNT && j < n_lv) n_pairs += 1u;
             if(j < n_lv){
                 float4 vp = bp.vtx_pos[path], vn = bp.vtx_nrm[path];
                 const LightVertexDev *lv = lvs + j;
@@ -763,6 +777,15 @@ void k_bdpt_connect(BdptSceneDev sc, PathBuf pb, BdptPathBuf bp, const LightVert
     }
     uint32_t n = s_n;
     if(threadIdx.x < n) evaluate(s_pair_path[threadIdx.x], (int) s_pair_j[threadIdx.x]);
+    if(COUNT){
+        unsigned long long v[8] = { n_pairs, n_survivors, n_shadow, n_lit, tally.nodes, tally.tris, tally.spheres, tally.group_boxes };
+        for(int k = 0; k < 8; ++k) for(int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        if((threadIdx.x & 63u) == 0u){
+            unsigned long long *dst[8] = { &wc->bd_pairs, &wc->bd_survivors, &wc->bd_shadow_rays, &wc->bd_unoccluded, &wc->bd_nodes, &wc->bd_tris,
+                                           &wc->bd_spheres, &wc->bd_group_boxes };
+            for(int k = 0; k < 8; ++k) if(v[k]) atomicAdd(dst[k], v[k]);
+        }
+    }
 }
 
 // total_L of one eye vertex: the table row summed in light-vertex order (the CPU loop's order, so the
@@ -854,14 +877,16 @@ void launch_bdpt_light_ctx(hipStream_t s, const LightVertexDev *lv, LightVertexC
 }
 void launch_bdpt_connect(hipStream_t s, const BdptSceneDev &sc, PathBuf pb, BdptPathBuf bp, const LightVertexDev *lv,
                          const LightVertexCtx *lctx, int n_lv, int light_depth, const uint32_t *cqueue, const uint32_t *ccount,
-                         uint32_t max_items, uint32_t slots, uint32_t max_groups){
+                         uint32_t max_items, uint32_t slots, uint32_t max_groups, WorkCounters *wc){
     unsigned long long waves = (unsigned long long) max_items * (((unsigned) n_lv + 63u) / 64u);
     unsigned long long g = (waves + (kBlock / 64) - 1) / (kBlock / 64);
     if(g < 1ull) g = 1ull;
     if(g > 4096ull) g = 4096ull;            // several trips per workgroup: the survivor list fills up across them
     const size_t stack_bytes = (size_t) (sc.stack_levels > 0 ? sc.stack_levels : kStackDepth) * kBlock * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_bdpt_connect, dim3(capped((uint32_t) g, max_groups)), dim3(kBlock), stack_bytes, s, sc, pb, bp, lv, lctx, n_lv, light_depth, cqueue, ccount,
-                       slots);
+    if(wc) hipLaunchKernelGGL((k_bdpt_connect<true>), dim3(capped((uint32_t) g, max_groups)), dim3(kBlock), stack_bytes, s, sc, pb, bp, lv, lctx, n_lv, light_depth,
+                              cqueue, ccount, slots, wc);
+    else hipLaunchKernelGGL((k_bdpt_connect<false>), dim3(capped((uint32_t) g, max_groups)), dim3(kBlock), stack_bytes, s, sc, pb, bp, lv, lctx, n_lv, light_depth,
+                            cqueue, ccount, slots, wc);
 }
 void launch_bdpt_reduce(hipStream_t s, PathBuf pb, BdptPathBuf bp, int n_lv, const uint32_t *cqueue, const uint32_t *ccount,
                         uint32_t max_items, uint32_t max_groups){

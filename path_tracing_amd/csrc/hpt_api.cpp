@@ -66,7 +66,7 @@ constexpr int kSplitHold = 0;
 // device memory per path slot of one pipeline (ensure_pass): path state 80 B, pending shadow ray 48 B, five queues of 4 B
 constexpr double kBytesPerPathSlot = 148.0;
 
-static_assert(sizeof(hpt_stats) == 248 && sizeof(hpt_params) == 40, "ABI records: keep path_tracing_amd/__init__.py and tests/test_boundary.py in step");
+static_assert(sizeof(hpt_stats) == 312 && sizeof(hpt_params) == 40, "ABI records: keep path_tracing_amd/__init__.py and tests/test_boundary.py in step");
 
 } // namespace
 
@@ -553,6 +553,9 @@ int collect_stats(hpt_scene *s){
     s->stats.lane_steps_shadow = wc.lane_steps_shadow; s->stats.wave_steps_shadow = wc.wave_steps_shadow;
     s->stats.leaf_lane_closest = wc.leaf_lane_closest; s->stats.leaf_wave_closest = wc.leaf_wave_closest;
     s->stats.leaf_lane_shadow = wc.leaf_lane_shadow; s->stats.leaf_wave_shadow = wc.leaf_wave_shadow;
+    s->stats.bd_pairs = wc.bd_pairs; s->stats.bd_survivors = wc.bd_survivors; s->stats.bd_shadow_rays = wc.bd_shadow_rays;
+    s->stats.bd_unoccluded = wc.bd_unoccluded; s->stats.bd_nodes = wc.bd_nodes; s->stats.bd_tris = wc.bd_tris;
+    s->stats.bd_spheres = wc.bd_spheres; s->stats.bd_group_boxes = wc.bd_group_boxes;
     s->stats_pending = false;
     return HPT_OK;
 }
@@ -719,7 +722,7 @@ int render_bdpt_local(hpt_scene *s, const void *camera, int W, int H, int eye_de
                                      s->cqueue, &ccnt[ci], eye_depth, P.max_delta, (uint32_t) slots, cam.eye); }
                 { LaunchTimer t(s, stream, timek, 2);
                   launch_bdpt_connect(stream, s->bd, s->pass[0].pb, s->bp, s->d_lv, s->d_lctx, n_lv, light_depth, s->cqueue, &ccnt[ci], nslots,
-                                      (uint32_t) slots, cap); }
+                                      (uint32_t) slots, cap, (P.flags & HPT_FLAG_COUNT_WORK) ? s->d_wc : nullptr); }
                 { LaunchTimer t(s, stream, timek, 3);
                   launch_bdpt_reduce(stream, s->pass[0].pb, s->bp, n_lv, s->cqueue, &ccnt[ci], nslots, cap); }
                 cur ^= 1;

@@ -53,7 +53,10 @@ struct PrimaryGen { Tiling tl; CameraDev cam; uint32_t first_sample; uint32_t pa
 struct WorkCounters {    // device counters, COUNT_WORK only
     unsigned long long boxes_closest, tris_closest, boxes_shadow, tris_shadow, closest_rays, shadow_rays, path_iters, samples,
                        lane_steps_closest, wave_steps_closest, lane_steps_shadow, wave_steps_shadow,
-                       leaf_lane_closest, leaf_wave_closest, leaf_lane_shadow, leaf_wave_shadow;
+                       leaf_lane_closest, leaf_wave_closest, leaf_lane_shadow, leaf_wave_shadow,
+                       // connection stage of the bidirectional path (k_bdpt_connect): candidate (eye vertex, light vertex) pairs, pairs that
+                       // pass the culls, shadow rays traced, unoccluded ones; node visits, triangle, sphere and group-box tests of those rays
+                       bd_pairs, bd_survivors, bd_shadow_rays, bd_unoccluded, bd_nodes, bd_tris, bd_spheres, bd_group_boxes;
 };
 
 // primitive code in PathBuf::hit.y

@@ -65,10 +65,47 @@ def bdpt_config(name, scene_file, W, H, spp, spl, reps=2):
     with hpt.Scene(L, sp, tr) as scene:
         scene.set_groups(*S.object_order(sc))
         ms, st = timed(scene, lambda f: scene.render_bdpt(cam, W, H, 4, 4, spp, spl, hpt.make_params(seed=1, flags=f)), reps)
+        cspp = min(spp, 4)                       # the counting render traces min(spp, 4) samples per pixel
+        scene.render_bdpt(cam, W, H, 4, 4, cspp, spl, hpt.make_params(seed=1, flags=hpt.FLAG_COUNT_WORK))
+        wc = scene.stats()
     n_lv = len(L) * spl * 4
+    k = spp / cspp
+    connect_s = st["ms_connect"] * 1e-3
+    # algorithmic bytes of the connection stage (what replaces the reference loop src/cpu_bdpt.cpp:387-440): a 16-B table entry per
+    # surviving pair + an 8-B validity word per 64 candidates + per shadow ray its two end points (24 B) and what its walk reads:
+    # 64-B nodes, 36-B triangles, 16-B spheres, 24-B group boxes
+    cbytes = k * (16.0 * wc["bd_survivors"] + 8.0 * wc["bd_pairs"] / 64.0 + 24.0 * wc["bd_shadow_rays"] + 64.0 * wc["bd_nodes"]
+                  + 36.0 * wc["bd_tris"] + 16.0 * wc["bd_spheres"] + 24.0 * wc["bd_group_boxes"])
+    # useful lane-operations: per node visit two slab tests, per triangle / sphere test, per surviving pair two BSDF values (~2 x 120),
+    # per unoccluded pair the MIS weight (two pdfs, ~2 x 90, and the ratio sums)
+    lane_ops = k * (2 * bench.LANE_OPS_PER_BOX * wc["bd_nodes"] + bench.LANE_OPS_PER_TRI * wc["bd_tris"] + 25.0 * wc["bd_spheres"]
+                    + 12.0 * wc["bd_group_boxes"] + 240.0 * wc["bd_survivors"] + 220.0 * wc["bd_unoccluded"] + 30.0 * wc["bd_pairs"])
+    pmc = None
+    try:
+        cand = json.load(open(os.path.join(HERE, "profiles", "r03_bdpt_pmc.json")))
+        if cand.get("kernel_source_sha") == bench.kernel_source_sha():
+            kc = cand["kernels"].get("k_bdpt_connect", {})
+            pmc = {"file": "profiles/r03_bdpt_pmc.json", "valu_issue_utilization": kc.get("valu_utilization"), "active_lanes": kc.get("valu_active_lanes_avg"),
+                   "note": "summed over the profiled BDPT renders (all three configurations)"}
+    except Exception:
+        pmc = None
     out[name] = {"ms": ms, "Msamples_per_s": W * H * spp / ms / 1e3, "light_vertices": n_lv,
                  "connections_per_s": W * H * spp * 4.0 * n_lv / ms / 1e3 if n_lv else None,
                  "kernels_last_render": kernel_classes(st, True),
+                 "connect_work_per_render": {"candidate_pairs": wc["bd_pairs"] * k, "pairs_after_culls": wc["bd_survivors"] * k,
+                                             "shadow_rays": wc["bd_shadow_rays"] * k, "unoccluded": wc["bd_unoccluded"] * k,
+                                             "nodes_per_shadow_ray": wc["bd_nodes"] / max(wc["bd_shadow_rays"], 1),
+                                             "tris_per_shadow_ray": wc["bd_tris"] / max(wc["bd_shadow_rays"], 1),
+                                             "spheres_per_shadow_ray": wc["bd_spheres"] / max(wc["bd_shadow_rays"], 1)},
+                 "roofline_connect": {"kernel": "k_bdpt_connect", "bound": "hbm", "binding_limit": "valu issue (culls, two BSDF values, MIS weight and the shadow walk per pair)",
+                                      "shadow_rays_per_s": wc["bd_shadow_rays"] * k / connect_s if connect_s > 0 else None,
+                                      "candidate_pairs_per_s": wc["bd_pairs"] * k / connect_s if connect_s > 0 else None,
+                                      "algorithmic_bytes_per_render": cbytes, "achieved_GBps": cbytes / connect_s / 1e9 if connect_s > 0 else None,
+                                      "peak_GBps": bench.HBM_PEAK_GBS, "frac": cbytes / connect_s / 1e9 / bench.HBM_PEAK_GBS if connect_s > 0 else None,
+                                      "valu_useful": {"achieved_T_lane_ops": lane_ops / connect_s / 1e12 if connect_s > 0 else None,
+                                                      "peak_T_lane_ops": bench.VALU_PEAK_LANE_OPS / 1e12,
+                                                      "frac": lane_ops / connect_s / bench.VALU_PEAK_LANE_OPS if connect_s > 0 else None},
+                                      "pmc": pmc},
                  "note": "connections_per_s counts every (eye vertex, light vertex) pair of up to 4 eye vertices per sample; "
                          "the connect kernel is VALU-bound (profiles/: SQ pass), its table traffic is streamed by k_bdpt_reduce"}
 

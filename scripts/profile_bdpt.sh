@@ -4,7 +4,7 @@
 # Usage on the GPU box: bash scripts/profile_bdpt.sh <tag>; then python scripts/profile_summarize_bdpt.py <tag>
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-TAG="${1:-r02_bdpt}"
+TAG="${1:-r03_bdpt}"
 OUT="$ROOT/gpurun_out/$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hpt):
 def test_params_struct_matches_header(hpt):
     assert C.sizeof(hpt.Params) == 40
     assert hpt.Stats.ms_total.offset == 64 and hpt.Stats.bvh_nodes.offset == 120
-    assert hpt.Stats.ms_resume.offset == 216 and C.sizeof(hpt.Stats) == 248      # static_assert in csrc/hpt_api.cpp
+    assert hpt.Stats.ms_resume.offset == 216 and C.sizeof(hpt.Stats) == 312      # static_assert in csrc/hpt_api.cpp
 
 
 def test_local_pixels_and_tiling_rules(hpt):

@@ -670,3 +670,27 @@ def test_no_host_wait_only_enqueues(hpt, sio):
     # enqueue about one).  The wall-clock split is recorded, not asserted: it depends on the box's load.
     assert pending[1], (host_ms, dev_ms)
     print("no_host_wait: host ms (default, blind) = %s, host+device ms = %s" % (host_ms, dev_ms))
+
+
+def test_bdpt_connection_work_counts(hpt, sio, oracle_mod):
+    """HPT_FLAG_COUNT_WORK on the bidirectional path: the connection stage reports its candidate pairs, the pairs that pass
+    the culls, the shadow rays it traces and their BVH work (the numerator of the BDPT roofline, scripts/bench_configs.py).
+    The shadow-ray count is checked against an independent one: the oracle's restated cpu_bdpt loop counts a connection
+    exactly where it calls its visibility test (reference src/cpu_bdpt.cpp:417-421); image unchanged by counting."""
+    sc = sio.load_scene(os.path.join(GOLDEN, "scenes", "input.txt"))
+    L, sp, tr = sio.flatten_for_pt(sc)
+    W, H, spp, spl = 48, 40, 2, 4
+    cam = sio.make_camera(sc.eye, sc.look_at, sc.view_up, sc.fov, W, H, tan_in_float=True)
+    ref, so = oracle_mod.bdpt_render(L, sp, tr, sio.object_order(sc), sc.eye, sc.look_at, sc.view_up, sc.fov, W, H, 4, 4, spp, spl, seed=8)
+    with hpt.Scene(L, sp, tr) as scene:
+        scene.set_groups(*sio.object_order(sc))
+        plain = scene.render_bdpt(cam, W, H, 4, 4, spp, spl, hpt.make_params(seed=8))
+        counted = scene.render_bdpt(cam, W, H, 4, 4, spp, spl, hpt.make_params(seed=8, flags=hpt.FLAG_COUNT_WORK))
+        st = scene.stats()
+    assert np.array_equal(plain, counted)
+    assert_parity(plain, ref)
+    n_lv = len(L) * spl * 4
+    assert st["bd_pairs"] % n_lv == 0 and st["bd_pairs"] > 0                   # every connected eye vertex meets every light vertex
+    assert st["bd_pairs"] >= st["bd_survivors"] >= st["bd_shadow_rays"] >= st["bd_unoccluded"] > 0
+    assert st["bd_shadow_rays"] == so["connections"] == so["shadow_rays"]
+    assert st["bd_group_boxes"] >= st["bd_shadow_rays"] and st["bd_nodes"] > 0 and st["bd_tris"] > 0
