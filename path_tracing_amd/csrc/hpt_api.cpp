@@ -63,6 +63,7 @@ struct TimedLaunch { hipEvent_t a, b; int cls; };
 // triangles, 16 spp: 29.9 ms split, 33.1 unsplit binary, 30.6 unsplit four-wide), so the hold-off is switched off; the
 // asynchronous read-back of the set-aside share stays (hpt_stats.long_rays_last_pass).
 constexpr int kSplitHold = 0;
+constexpr int kMaxPipes = 4;             // passes of a render in flight at a time, at most (default 2; development: flags bits 29-30)
 // device memory per path slot of one pipeline (ensure_pass): path state 80 B, pending shadow ray 48 B, five queues of 4 B
 constexpr double kBytesPerPathSlot = 148.0;
 
@@ -97,9 +98,9 @@ struct hpt_scene {
         uint32_t *deep_stack = nullptr;              // stack levels of the resume launch past its LDS share (launch_trace_resume)
         uint32_t *counters = nullptr; int n_counters = 0;
         uint32_t *h_count = nullptr;                 // pinned read-back word
-    } pass[2];
+    } pass[kMaxPipes];
     size_t cap_local = 0;
-    hipStream_t p2_stream = nullptr; int p2_priority = 0; hipEvent_t p2_fork = nullptr, p2_done = nullptr;
+    hipStream_t px_stream[kMaxPipes] = {}; int px_priority[kMaxPipes] = {}; hipEvent_t px_fork = nullptr, px_done[kMaxPipes] = {};   // pipelines 1..: own streams
     const uint32_t *last_counters = nullptr;     // counters of the last pass rendered (either pipeline)
     float4 *accum = nullptr;
     WorkCounters *d_wc = nullptr;
@@ -167,27 +168,30 @@ int ensure_pass(PassBuffers &w, size_t paths, int n_counters){
     return HPT_OK;
 }
 
-// stream and events of the second pipeline
-int ensure_pipe2(hpt_scene *s, hipStream_t caller){
-    // The two pipelines only overlap if their streams sit on different hardware queues.  The runtime maps streams
+// streams and events of the pipelines past the first (which runs on the caller's stream)
+int ensure_pipes(hpt_scene *s, hipStream_t caller, int npipes){
+    // The pipelines only overlap if their streams sit on different hardware queues.  The runtime maps streams
     // of one priority onto a small pool of queues (GPU_MAX_HW_QUEUES, 4 by default) by reference count, so once a
     // process holds a few more streams -- RCCL's, after a communicator exists -- a second stream of the caller's
     // priority can land on the caller's queue and the passes serialise (measured: 169 ms per config-3 render
     // instead of 161).  Streams of another priority come from another pool: the second pipeline takes the highest
-    // priority unless the caller's stream already has it, then the default one.
+    // priority unless the caller's stream already has it, then the default one; further pipelines take the remaining levels in turn.
     int pr_least = 0, pr_greatest = 0, pr_caller = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
     if(hipStreamGetPriority(caller, &pr_caller) != hipSuccess){ (void) hipGetLastError(); pr_caller = 0; }
-    const int want = (pr_caller == pr_greatest && pr_greatest != 0) ? 0 : pr_greatest;
-    if(s->p2_stream && s->p2_priority != want){ hipStreamSynchronize(s->p2_stream); hipStreamDestroy(s->p2_stream); s->p2_stream = nullptr; }
-    if(!s->p2_stream){
-        HIP_TRY(hipStreamCreateWithPriority(&s->p2_stream, hipStreamNonBlocking, want));
-        s->p2_priority = want;
+    std::vector<int> levels;                                   // every level but the caller's, highest first
+    for(int l = pr_greatest; l <= pr_least; ++l) if(l != pr_caller) levels.push_back(l);
+    if(levels.empty()) levels.push_back(pr_caller);
+    for(int k = 1; k < npipes; ++k){
+        const int want = levels[(size_t) (k - 1) % levels.size()];
+        if(s->px_stream[k] && s->px_priority[k] != want){ hipStreamSynchronize(s->px_stream[k]); hipStreamDestroy(s->px_stream[k]); s->px_stream[k] = nullptr; }
+        if(!s->px_stream[k]){
+            HIP_TRY(hipStreamCreateWithPriority(&s->px_stream[k], hipStreamNonBlocking, want));
+            s->px_priority[k] = want;
+        }
+        if(!s->px_done[k]) HIP_TRY(hipEventCreateWithFlags(&s->px_done[k], hipEventDisableTiming));
     }
-    if(!s->p2_fork){
-        HIP_TRY(hipEventCreateWithFlags(&s->p2_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&s->p2_done, hipEventDisableTiming));
-    }
+    if(!s->px_fork) HIP_TRY(hipEventCreateWithFlags(&s->px_fork, hipEventDisableTiming));
     return HPT_OK;
 }
 
@@ -281,19 +285,20 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     // is such a render (rank 0 of 4 at config 3, 64 Mi slots: one pass 37.2-37.4 ms, two half passes 35.3-36.5; of 2:
     // 72.1 -> 68.2; of 8: 19.5 -> 18.7; on another box 35.4 against 35.6: never a loss beyond the noise) -- unless it is
     // so small (< 1 Mi slots) that launch latencies are what it costs.
-    bool dual = !(flags & HPT_FLAG_SINGLE_PIPELINE) && !count && !legacy;
+    int npipes = (!(flags & HPT_FLAG_SINGLE_PIPELINE) && !count && !legacy) ? 2 + ((flags >> 29) & 3) : 1;     // flags bits 29-30 (development): 3 or 4 pipelines
+    if(npipes > kMaxPipes) npipes = kMaxPipes;
     int spass = P.samples_per_pass;
     if(spass <= 0){
         long long target = 128ll << 20;
         // ... on a device that has the memory for it: when the workspace would have to grow, the pass is sized so that
         // both pipelines' state fits in 70 % of what is free now plus what the scene already holds (a smaller device,
         // or several scenes on one device, get smaller passes instead of HPT_ERR_NOMEM; the image does not depend on it)
-        const size_t have = s->pass[0].cap_paths + s->pass[1].cap_paths;
+        size_t have = 0; for(const PassBuffers &w : s->pass) have += w.cap_paths;
         if((size_t) std::min<long long>(target, (long long) tl.n_local * spp) > s->pass[0].cap_paths){
             size_t free_b = 0, total_b = 0;
             if(hipMemGetInfo(&free_b, &total_b) == hipSuccess){
                 const double usable = 0.7 * ((double) free_b + (double) have * kBytesPerPathSlot);
-                const long long fit = (long long) (usable / (kBytesPerPathSlot * (dual ? 2.0 : 1.0)));
+                const long long fit = (long long) (usable / (kBytesPerPathSlot * (double) npipes));
                 if(fit < target){
                     target = std::max<long long>(fit, tl.n_local);
                     // a workspace sized this way earlier is kept (no reallocation for a few per cent more)
@@ -303,22 +308,23 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         }
         spass = (int) std::max<long long>(1, target / tl.n_local);
         spass = std::min(spass, spp);
-        if(dual && spass == spp && spp >= 2 && (long long) tl.n_local * spp >= (1ll << 20)) spass = (spp + 1) / 2;
+        // every round of the render keeps all pipelines busy: the passes of the render are cut to a multiple of their number
+        if(npipes > 1 && spp >= npipes && (long long) tl.n_local * spp >= (1ll << 20)){
+            const int rounds = (spp + spass * npipes - 1) / (spass * npipes);
+            spass = (spp + rounds * npipes - 1) / (rounds * npipes);
+        }
     }
     spass = std::min(spass, spp);
     const int npass = (spp + spass - 1) / spass;
-    if(npass < 2) dual = false;
+    if(npass < npipes) npipes = npass;
     size_t paths = (size_t) tl.n_local * spass;
     if(paths > 0x7FFFFFF0ull) return fail(HPT_ERR_INVALID, "too many path slots per pass");
     int max_iters = eye_depth + P.max_delta + 1;
     int n_counters = 4 * (max_iters + 2);
     rc = ensure_workspace(s, paths, tl.n_local, n_counters);
     if(rc) return rc;
-    if(dual){
-        rc = ensure_pass(s->pass[1], paths, n_counters);
-        if(rc == HPT_OK) rc = ensure_pipe2(s, stream);
-        if(rc) return rc;
-    }
+    for(int k = 1; k < npipes; ++k){ rc = ensure_pass(s->pass[k], paths, n_counters); if(rc) return rc; }
+    if(npipes > 1){ rc = ensure_pipes(s, stream, npipes); if(rc) return rc; }
 
     WorkCounters *wc = count ? s->d_wc : nullptr;
     s->timed.clear(); s->event_next = 0;
@@ -365,14 +371,14 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         int sthis = 0, cur = 0, pending_shadow = -1; uint32_t slots = 0; PrimaryGen primary{};
         uint32_t *qcnt = nullptr, *scnt = nullptr, *lecnt = nullptr, *lscnt = nullptr;
     };
-    Pass pipe[2]{};
-    for(int k = 0; k < (dual ? 2 : 1); ++k){
+    Pass pipe[kMaxPipes]{};
+    for(int k = 0; k < npipes; ++k){
         const PassBuffers &w = s->pass[k];
         Pass &q = pipe[k];
         q.pb = w.pb; q.sb = w.sb; q.queue[0] = w.queue[0]; q.queue[1] = w.queue[1]; q.squeue = w.squeue;
         q.lqueue[0] = w.lqueue[0]; q.lqueue[1] = w.lqueue[1];
         q.deep_stack = ((flags >> 18) & 1) ? nullptr : w.deep_stack;      // flags bits 16-31: development switches (bit 18: whole stack in LDS; bit 19: two levels in LDS; bit 20: binary resume launch; bits 21-28: its tuning)
-        q.counters = w.counters; q.h_count = w.h_count; q.st = k == 0 ? stream : s->p2_stream;
+        q.counters = w.counters; q.h_count = w.h_count; q.st = k == 0 ? stream : s->px_stream[k];
     }
     for(Pass &q : pipe){
         if(!q.counters) continue;
@@ -440,8 +446,9 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
     // (include/hpt.h); a scene without delta materials never gets here with a non-empty queue and pays one read-back.
     const bool no_host_wait = (flags & HPT_FLAG_NO_HOST_WAIT) != 0;     // enqueue every tail iteration unseen
     auto tails = [&](int npipes) -> int {
-        bool live[2] = { npipes > 0, npipes > 1 };
-        for(int it = eye_depth; it < max_iters && (live[0] || live[1]); ++it){
+        bool live[kMaxPipes]; int nlive = npipes;
+        for(int k = 0; k < kMaxPipes; ++k) live[k] = k < npipes;
+        for(int it = eye_depth; it < max_iters && nlive > 0; ++it){
             const bool look = !no_host_wait && ((it - eye_depth) & 1) == 0;
             if(look) for(int k = 0; k < npipes; ++k) if(live[k])
                 HIP_TRY(hipMemcpyAsync(pipe[k].h_count, &pipe[k].qcnt[it], sizeof(uint32_t), hipMemcpyDeviceToHost, pipe[k].st));
@@ -449,7 +456,7 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
                 if(!live[k]) continue;
                 if(look){
                     HIP_TRY(hipStreamSynchronize(pipe[k].st));
-                    if(*pipe[k].h_count == 0u){ live[k] = false; continue; }
+                    if(*pipe[k].h_count == 0u){ live[k] = false; --nlive; continue; }
                 }
                 iteration(pipe[k], it);
             }
@@ -469,31 +476,28 @@ int render_local(hpt_scene *s, const void *camera, int W, int H, int eye_depth, 
         return HPT_OK;
     };
 
-    for(int done = 0; done < spp; done += spass * (dual ? 2 : 1)){
-        const bool second = dual && done + spass < spp;
-        if(second){
-            // the second pipeline starts after everything already queued on the caller's stream (the previous
-            // resolve of its radiance buffer included)
-            HIP_TRY(hipEventRecord(s->p2_fork, stream));
-            HIP_TRY(hipStreamWaitEvent(s->p2_stream, s->p2_fork, 0));
+    for(int done = 0; done < spp; done += spass * npipes){
+        int active = 0;                                     // pipelines with a pass in this round
+        while(active < npipes && done + active * spass < spp) ++active;
+        if(active > 1){
+            // the other pipelines start after everything already queued on the caller's stream (the previous
+            // resolve of their radiance buffers included)
+            HIP_TRY(hipEventRecord(s->px_fork, stream));
+            for(int k = 1; k < active; ++k) HIP_TRY(hipStreamWaitEvent(s->px_stream[k], s->px_fork, 0));
         }
-        rc = begin_pass(pipe[0], done); if(rc) return rc;
-        if(second){ rc = begin_pass(pipe[1], done + spass); if(rc) return rc; }
-        for(int it = 0; it < eye_depth && it < max_iters; ++it){
-            iteration(pipe[0], it);
-            if(second) iteration(pipe[1], it);
-        }
-        rc = tails(second ? 2 : 1); if(rc) return rc;
-        // the per-pixel sums are added in sample order: this pass, then the other pipeline's
-        { LaunchTimer t(s, stream, timek, 3);
-          launch_resolve(stream, tl, pipe[0].pb, s->accum, pipe[0].sthis); }
-        s->last_counters = pipe[0].counters;
-        if(second){
-            HIP_TRY(hipEventRecord(s->p2_done, s->p2_stream));
-            HIP_TRY(hipStreamWaitEvent(stream, s->p2_done, 0));
+        for(int k = 0; k < active; ++k){ rc = begin_pass(pipe[k], done + k * spass); if(rc) return rc; }
+        for(int it = 0; it < eye_depth && it < max_iters; ++it)
+            for(int k = 0; k < active; ++k) iteration(pipe[k], it);
+        rc = tails(active); if(rc) return rc;
+        // the per-pixel sums are added in sample order: pipeline 0's pass, then the next one's, ...
+        for(int k = 0; k < active; ++k){
+            if(k > 0){
+                HIP_TRY(hipEventRecord(s->px_done[k], s->px_stream[k]));
+                HIP_TRY(hipStreamWaitEvent(stream, s->px_done[k], 0));
+            }
             LaunchTimer t(s, stream, timek, 3);
-            launch_resolve(stream, tl, pipe[1].pb, s->accum, pipe[1].sthis);
-            s->last_counters = pipe[1].counters;
+            launch_resolve(stream, tl, pipe[k].pb, s->accum, pipe[k].sthis);
+            s->last_counters = pipe[k].counters;
         }
     }
     float divisor = (flags & HPT_FLAG_OUTPUT_SUM) ? 1.0f : (float) spp;
@@ -901,9 +905,11 @@ void hpt_scene_destroy(hpt_scene *s){
         if(w.h_count) hipHostFree(w.h_count);
     }
     hipFree(s->accum); hipFree(s->d_wc);
-    if(s->p2_fork) hipEventDestroy(s->p2_fork);
-    if(s->p2_done) hipEventDestroy(s->p2_done);
-    if(s->p2_stream) hipStreamDestroy(s->p2_stream);
+    if(s->px_fork) hipEventDestroy(s->px_fork);
+    for(int k = 1; k < kMaxPipes; ++k){
+        if(s->px_done[k]) hipEventDestroy(s->px_done[k]);
+        if(s->px_stream[k]) hipStreamDestroy(s->px_stream[k]);
+    }
     if(s->h_split) hipHostFree(s->h_split);
     if(s->ev_split) hipEventDestroy(s->ev_split);
     hipFree(s->d_local_own); hipFree(s->d_image_own);
