@@ -40,8 +40,8 @@ int fail(int code, const std::string &msg){ g_err = msg; return code; }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) \
     return fail(e_ == hipErrorOutOfMemory ? HPT_ERR_NOMEM : HPT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while(0)
 
-template <typename T>
-hipError_t upload(const std::vector<T> &v, T **dptr){
+template <typename T, typename A>
+hipError_t upload(const std::vector<T, A> &v, T **dptr){
     *dptr = nullptr;
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
     hipError_t e = hipMalloc((void **) dptr, bytes);

@@ -9,6 +9,8 @@
 //   light        112 B  CudaLight with the per-light invariants hoisted
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace hpt {
@@ -20,6 +22,19 @@ constexpr int kMaxBvhDepth = 30;              // traversal stack holds kStackDep
 constexpr int kStackDepth = 32;
 
 struct Float4 { float x, y, z, w; };
+
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the scene arrays are tens to hundreds of
+// megabytes, every element is written by the (multi-threaded) build, and a zero fill by the one thread that resizes them --
+// page faults included -- was a fifth of the build
+template <typename T>
+struct default_init_allocator : std::allocator<T> {
+    template <typename U> struct rebind { using other = default_init_allocator<U>; };
+    default_init_allocator() = default;
+    template <typename U> default_init_allocator(const default_init_allocator<U> &){}
+    template <typename U> void construct(U *p){ ::new((void *) p) U; }
+    template <typename U, typename... A> void construct(U *p, A &&... a){ ::new((void *) p) U(std::forward<A>(a)...); }
+};
+template <typename T> using pod_vector = std::vector<T, default_init_allocator<T>>;
 
 struct BvhNode {           // 64 B
     float lmin[3]; uint32_t left;
@@ -79,12 +94,12 @@ static_assert(sizeof(DevMaterial) == 48 && sizeof(DevLight) == 112, "layout");
 
 // Host-side flattened scene, ready to upload.
 struct HostScene {
-    std::vector<BvhNode> nodes;        // nodes[0] is the root (always an inner node)
-    std::vector<QBvhNode> qnodes;      // same tree, quantised boxes
-    std::vector<WideNode> wnodes;      // four-wide collapse of it (development A/B)
+    pod_vector<BvhNode> nodes;         // nodes[0] is the root (always an inner node)
+    pod_vector<QBvhNode> qnodes;       // same tree, quantised boxes
+    pod_vector<WideNode> wnodes;       // four-wide collapse of it (the resume launch's tree)
     int wide_depth = 0;
     float qorigin[3] = {0, 0, 0}, qscale[3] = {1, 1, 1};   // grid: coordinate = qorigin + q * qscale
-    std::vector<DevTriangle> tris;     // leaf order
+    pod_vector<DevTriangle> tris;      // leaf order
     std::vector<DevRound> rounds;      // spheres, then light balls
     std::vector<DevMaterial> materials;
     std::vector<DevLight> lights;

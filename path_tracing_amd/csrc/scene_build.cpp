@@ -140,8 +140,9 @@ void parallel_chunks(size_t n, F fn){
 }
 
 struct Builder {
-    std::vector<Prim> prims;
-    std::vector<BvhNode> nodes;       // pre-sized by the caller; slots are handed out by next_node
+    pod_vector<Prim> prims;
+    pod_vector<BvhNode> nodes;        // pre-sized by the caller; slots are handed out by next_node
+    pod_vector<Prim> scratch;         // the big nodes' partition buffer (sized once, by the root)
     std::atomic<uint32_t> next_node{0};
     std::atomic<int> max_depth_seen{0};
     float pad_abs = 0.0f;
@@ -190,13 +191,11 @@ struct Builder {
         while(depth > seen && !max_depth_seen.compare_exchange_weak(seen, depth, std::memory_order_relaxed)){}
     }
 
-    // Builds the subtree over prims[first, first+count); returns its child code and box.
-    uint32_t build(int first, int count, int depth, Box &out_box, int par_levels = -1){
-        if(par_levels < 0) par_levels = parallel_levels();
-        note_depth(depth);
-        Box bb; bb.reset();
-        Box cb; cb.reset();
-        if(par_levels > 0 && (size_t) count >= kBigNode){
+    // Bounds (primitive boxes, centroids) of prims[first, first+count): the root's only -- every other node gets its own from the
+    // partition that made it.
+    void range_bounds(int first, int count, Box &bb, Box &cb, bool parallel){
+        bb.reset(); cb.reset();
+        if(parallel && (size_t) count >= kBigNode){
             std::vector<Box> pb((size_t) kChunks), pc((size_t) kChunks);
             for(int c = 0; c < kChunks; ++c){ pb[(size_t) c].reset(); pc[(size_t) c].reset(); }
             parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){
@@ -205,7 +204,23 @@ struct Builder {
             for(int c = 0; c < kChunks; ++c){ bb.grow(pb[(size_t) c]); cb.grow(pc[(size_t) c]); }
         } else
         for(int i = first; i < first + count; ++i){ bb.grow(prims[i].box); cb.grow(prims[i].cen); }
+    }
+
+    uint32_t build(int first, int count, int depth, Box &out_box, int par_levels = -1){
+        if(par_levels < 0) par_levels = parallel_levels();
+        if(par_levels > 0 && (size_t) count >= kBigNode && scratch.size() < prims.size()) scratch.resize(prims.size());    // before any thread is started
+        Box bb, cb;
+        range_bounds(first, count, bb, cb, par_levels > 0);
         out_box = bb;
+        return build_node(first, count, depth, bb, cb, par_levels);
+    }
+
+    struct Bins { Box box[3][kBins]; int cnt[3][kBins]; void reset(){ for(int a = 0; a < 3; ++a) for(int b = 0; b < kBins; ++b){ box[a][b].reset(); cnt[a][b] = 0; } } };
+
+    // Builds the subtree over prims[first, first+count) whose primitive boxes span bb and whose centroids span cb; returns its
+    // child code.  One pass bins the range on all three axes, one pass partitions it and gathers the two children's bounds.
+    uint32_t build_node(int first, int count, int depth, const Box &bb, const Box &cb, int par_levels){
+        note_depth(depth);
         if(count <= max_leaf) return make_leaf(first, count);
 
         // levels still available below this node; force balanced splits when they run short
@@ -219,75 +234,89 @@ struct Builder {
         if(ext[1] > ext[axis]) axis = 1;
         if(ext[2] > ext[axis]) axis = 2;
 
+        const bool big = par_levels > 0 && (size_t) count >= kBigNode;        // the few nodes at the top of a large tree
         int mid = -1;
+        Box lbb, lcb, rbb, rcb; lbb.reset(); lcb.reset(); rbb.reset(); rcb.reset();
         if(!force_median && ext[axis] > 0.0f){
-            float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
-            const bool big = par_levels > 0 && (size_t) count >= kBigNode;        // the few nodes at the top of a large tree
-            for(int ax = 0; ax < 3; ++ax){
-                if(!(ext[ax] > 0.0f)) continue;
-                Box bin_box[kBins]; int bin_cnt[kBins];
-                for(int b = 0; b < kBins; ++b){ bin_box[b].reset(); bin_cnt[b] = 0; }
-                float scale = (float) kBins / ext[ax];
-                if(big){
-                    // per-chunk bins merged afterwards: boxes grow by min / max and counts add, so the result is the serial one
-                    std::vector<Box> cbox((size_t) kChunks * kBins); std::vector<int> ccnt((size_t) kChunks * kBins, 0);
-                    for(Box &b : cbox) b.reset();
-                    parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){
-                        Box *bb = &cbox[(size_t) c * kBins]; int *bc = &ccnt[(size_t) c * kBins];
-                        for(size_t i = (size_t) first + b0; i < (size_t) first + e0; ++i){
-                            int b = (int) ((prims[i].cen[ax] - cb.mn[ax]) * scale);
-                            b = std::min(std::max(b, 0), kBins - 1);
-                            bb[b].grow(prims[i].box); bc[b]++;
-                        }
-                    });
-                    for(int c = 0; c < kChunks; ++c) for(int b = 0; b < kBins; ++b){ bin_box[b].grow(cbox[(size_t) c * kBins + b]); bin_cnt[b] += ccnt[(size_t) c * kBins + b]; }
-                } else
-                for(int i = first; i < first + count; ++i){
-                    int b = (int) ((prims[i].cen[ax] - cb.mn[ax]) * scale);
-                    b = std::min(std::max(b, 0), kBins - 1);
-                    bin_box[b].grow(prims[i].box); bin_cnt[b]++;
+            float scale[3]; bool use[3];
+            for(int ax = 0; ax < 3; ++ax){ use[ax] = ext[ax] > 0.0f; scale[ax] = use[ax] ? (float) kBins / ext[ax] : 0.0f; }
+            auto bin_range = [&](Bins &bins, size_t b0, size_t e0){
+                for(size_t i = b0; i < e0; ++i){
+                    const Prim &p = prims[i];
+                    for(int ax = 0; ax < 3; ++ax){
+                        if(!use[ax]) continue;
+                        int b = (int) ((p.cen[ax] - cb.mn[ax]) * scale[ax]);
+                        b = std::min(std::max(b, 0), kBins - 1);
+                        bins.box[ax][b].grow(p.box); bins.cnt[ax][b]++;
+                    }
                 }
+            };
+            Bins bins; bins.reset();
+            if(big){
+                // per-chunk bins merged afterwards: boxes grow by min / max and counts add, so the result is the serial one
+                std::vector<Bins> part((size_t) kChunks);
+                for(Bins &b : part) b.reset();
+                parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){ bin_range(part[(size_t) c], (size_t) first + b0, (size_t) first + e0); });
+                for(const Bins &pb : part) for(int ax = 0; ax < 3; ++ax) for(int b = 0; b < kBins; ++b){ bins.box[ax][b].grow(pb.box[ax][b]); bins.cnt[ax][b] += pb.cnt[ax][b]; }
+            } else bin_range(bins, (size_t) first, (size_t) first + (size_t) count);
+
+            float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+            for(int ax = 0; ax < 3; ++ax){
+                if(!use[ax]) continue;
                 float right_area[kBins]; int right_cnt[kBins];
                 Box acc; acc.reset(); int c = 0;
                 for(int b = kBins - 1; b > 0; --b){
-                    acc.grow(bin_box[b]); c += bin_cnt[b];
+                    acc.grow(bins.box[ax][b]); c += bins.cnt[ax][b];
                     right_area[b] = acc.half_area(); right_cnt[b] = c;
                 }
                 acc.reset(); c = 0;
                 for(int b = 0; b < kBins - 1; ++b){
-                    acc.grow(bin_box[b]); c += bin_cnt[b];
+                    acc.grow(bins.box[ax][b]); c += bins.cnt[ax][b];
                     if(c == 0 || right_cnt[b + 1] == 0) continue;
                     float cost = acc.half_area() * (float) c + right_area[b + 1] * (float) right_cnt[b + 1];
                     if(cost < best_cost){ best_cost = cost; best_axis = ax; best_bin = b; }
                 }
             }
             if(best_axis >= 0){
-                float scale = (float) kBins / ext[best_axis];
-                float lo = cb.mn[best_axis];
+                const float sc = scale[best_axis], lo = cb.mn[best_axis];
                 auto goes_left = [&](const Prim &p){
-                    int b = (int) ((p.cen[best_axis] - lo) * scale);
+                    int b = (int) ((p.cen[best_axis] - lo) * sc);
                     b = std::min(std::max(b, 0), kBins - 1);
                     return b <= best_bin;
                 };
                 if(big){
-                    // stable partition through a scratch copy: every chunk counts, then scatters to the offsets the counts give
+                    // stable partition through a scratch copy: every chunk counts (and gathers the children's bounds), then
+                    // scatters to the offsets the counts give
                     std::vector<size_t> nleft((size_t) kChunks, 0), nall((size_t) kChunks, 0);
+                    std::vector<Box> cl((size_t) kChunks), ccl((size_t) kChunks), cr((size_t) kChunks), ccr((size_t) kChunks);
+                    for(int c = 0; c < kChunks; ++c){ cl[(size_t) c].reset(); ccl[(size_t) c].reset(); cr[(size_t) c].reset(); ccr[(size_t) c].reset(); }
                     parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){
-                        size_t l = 0; for(size_t i = (size_t) first + b0; i < (size_t) first + e0; ++i) l += goes_left(prims[i]) ? 1 : 0;
+                        size_t l = 0;
+                        for(size_t i = (size_t) first + b0; i < (size_t) first + e0; ++i){
+                            const Prim &p = prims[i];
+                            if(goes_left(p)){ ++l; cl[(size_t) c].grow(p.box); ccl[(size_t) c].grow(p.cen); } else { cr[(size_t) c].grow(p.box); ccr[(size_t) c].grow(p.cen); }
+                        }
                         nleft[(size_t) c] = l; nall[(size_t) c] = e0 - b0;
                     });
                     size_t total_left = 0; for(size_t l : nleft) total_left += l;
+                    for(int c = 0; c < kChunks; ++c){ lbb.grow(cl[(size_t) c]); lcb.grow(ccl[(size_t) c]); rbb.grow(cr[(size_t) c]); rcb.grow(ccr[(size_t) c]); }
                     std::vector<size_t> loff((size_t) kChunks), roff((size_t) kChunks);
                     { size_t l = 0, r = total_left; for(int c = 0; c < kChunks; ++c){ loff[(size_t) c] = l; roff[(size_t) c] = r; l += nleft[(size_t) c]; r += nall[(size_t) c] - nleft[(size_t) c]; } }
-                    std::vector<Prim> tmp((size_t) count);
+                    // (the scratch range [first, first + count) belongs to this node alone: big nodes working at once are disjoint)
+                    Prim *tmp = scratch.data() + first;
                     parallel_chunks((size_t) count, [&](int c, size_t b0, size_t e0){
                         size_t l = loff[(size_t) c], r = roff[(size_t) c];
                         for(size_t i = (size_t) first + b0; i < (size_t) first + e0; ++i){ if(goes_left(prims[i])) tmp[l++] = prims[i]; else tmp[r++] = prims[i]; }
                     });
-                    parallel_chunks((size_t) count, [&](int, size_t b0, size_t e0){ std::copy(tmp.begin() + (long) b0, tmp.begin() + (long) e0, prims.begin() + first + (long) b0); });
+                    parallel_chunks((size_t) count, [&](int, size_t b0, size_t e0){ std::copy(tmp + b0, tmp + e0, prims.begin() + first + (long) b0); });
                     mid = first + (int) total_left;
                 } else {
-                    auto it = std::partition(prims.begin() + first, prims.begin() + first + count, goes_left);
+                    // std::partition applies the predicate to every element exactly once: the children's bounds are gathered on the way
+                    auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p){
+                        const bool l = goes_left(p);
+                        if(l){ lbb.grow(p.box); lcb.grow(p.cen); } else { rbb.grow(p.box); rcb.grow(p.cen); }
+                        return l;
+                    });
                     mid = (int) (it - prims.begin());
                 }
                 if(mid == first || mid == first + count) mid = -1;
@@ -301,23 +330,24 @@ struct Builder {
                                  if(a.cen[axis] != b.cen[axis]) return a.cen[axis] < b.cen[axis];
                                  return a.index < b.index;
                              });
+            range_bounds(first, mid - first, lbb, lcb, false);
+            range_bounds(mid, first + count - mid, rbb, rcb, false);
         }
 
         uint32_t me = alloc_node();
         // (children return codes that already include node_base / tri_base)
-        Box lb, rb;
         uint32_t lc, rc;
         if(par_levels > 0 && count > kParallelMin){
-            std::thread left([&](){ lc = build(first, mid - first, depth + 1, lb, par_levels - 1); });
-            rc = build(mid, first + count - mid, depth + 1, rb, par_levels - 1);
+            std::thread left([&](){ lc = build_node(first, mid - first, depth + 1, lbb, lcb, par_levels - 1); });
+            rc = build_node(mid, first + count - mid, depth + 1, rbb, rcb, par_levels - 1);
             left.join();
         } else {
-            lc = build(first, mid - first, depth + 1, lb, 0);
-            rc = build(mid, first + count - mid, depth + 1, rb, 0);
+            lc = build_node(first, mid - first, depth + 1, lbb, lcb, 0);
+            rc = build_node(mid, first + count - mid, depth + 1, rbb, rcb, 0);
         }
         BvhNode &n = nodes[me];
-        write_box(n.lmin, n.lmax, lb); n.left = lc;
-        write_box(n.rmin, n.rmax, rb); n.right = rc;
+        write_box(n.lmin, n.lmax, lbb); n.left = lc;
+        write_box(n.rmin, n.rmax, rbb); n.right = rc;
         n.pad0 = n.pad1 = 0;
         return me + node_base;
     }
@@ -467,17 +497,38 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
     {   // breadth-first renumbering: node 0 stays the root and every node of depth d precedes every node of depth d + 1,
         // so the nodes a ray can reach in its first k steps are the first 2^k - 1 at most (k_trace keeps those in LDS)
         const size_t n = hs.nodes.size();
-        std::vector<uint32_t> order; order.reserve(n);
-        std::vector<uint32_t> new_index(n, 0u);
-        order.push_back(0u);
-        for(size_t head = 0; head < order.size(); ++head){
-            const BvhNode &nd = hs.nodes[order[head]];
-            for(uint32_t c : { nd.left, nd.right })
-                if(c != kEmptyChild && !(c & kLeafFlag)){ new_index[c] = (uint32_t) order.size(); order.push_back(c); }
+        pod_vector<uint32_t> order(n);
+        pod_vector<uint32_t> new_index(n);
+        auto inner = [](uint32_t c){ return c != kEmptyChild && !(c & kLeafFlag); };
+        // level by level: the inner children of a level, in order, are the next level; a level is cut into chunks that count
+        // their children, a prefix sum places them, and the chunks fill their part
+        size_t lvl_begin = 0, lvl_end = 1;
+        order[0] = 0u;
+        while(lvl_begin < lvl_end){
+            const size_t cnt = lvl_end - lvl_begin;
+            size_t per_chunk[kChunks] = {};
+            parallel_chunks(cnt, [&](int c, size_t b0, size_t e0){
+                size_t k = 0;
+                for(size_t i = b0; i < e0; ++i){ const BvhNode &nd = hs.nodes[order[lvl_begin + i]]; k += (inner(nd.left) ? 1u : 0u) + (inner(nd.right) ? 1u : 0u); }
+                per_chunk[c] = k;
+            });
+            size_t offs[kChunks], total = 0;
+            for(int c = 0; c < kChunks; ++c){ offs[c] = total; total += per_chunk[c]; }
+            if(lvl_end + total > n) return "internal error: BVH has more reachable nodes than slots";
+            parallel_chunks(cnt, [&](int c, size_t b0, size_t e0){
+                size_t o = lvl_end + offs[c];
+                for(size_t i = b0; i < e0; ++i){
+                    const BvhNode &nd = hs.nodes[order[lvl_begin + i]];
+                    if(inner(nd.left)){ new_index[nd.left] = (uint32_t) o; order[o++] = nd.left; }
+                    if(inner(nd.right)){ new_index[nd.right] = (uint32_t) o; order[o++] = nd.right; }
+                }
+            });
+            lvl_begin = lvl_end; lvl_end += total;
         }
+        order.resize(lvl_end);
         // (slots a build thread reserved and did not use are not reachable and drop out here)
         const size_t reachable = order.size();
-        std::vector<BvhNode> sorted(reachable);
+        pod_vector<BvhNode> sorted(reachable);
         parallel_chunks(reachable, [&](int, size_t b0, size_t e0){
             for(size_t i = b0; i < e0; ++i){
                 BvhNode nd = hs.nodes[order[i]];
@@ -532,37 +583,58 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
         auto qlo = [&](float v, int a){ double q = std::floor(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) - 1.0; return (uint32_t) std::min(65535.0, std::max(0.0, q)); };
         auto qhi = [&](float v, int a){ double q = std::ceil(((double) v - (double) hs.qorigin[a]) / (double) hs.qscale[a]) + 1.0; return (uint32_t) std::min(65535.0, std::max(0.0, q)); };
         struct Kids { Kid k[4]; int n; uint32_t code[4]; };
-        std::vector<uint32_t> todo{0u};            // binary node each wide node was collapsed from
-        std::vector<int> depth{1};
-        std::vector<Kids> all; all.reserve(hs.nodes.size() / 2 + 1);
-        // pass 1 (serial, breadth-first): which child boxes a wide node holds and the numbers of its inner children
-        for(size_t qi = 0; qi < todo.size(); ++qi){
-            Kids ks; ks.n = 0;
-            auto open = [&](uint32_t idx){
-                const BvhNode &b = hs.nodes[idx];
-                if(b.left != kEmptyChild) ks.k[ks.n++] = Kid{ b.lmin, b.lmax, b.left };
-                if(b.right != kEmptyChild) ks.k[ks.n++] = Kid{ b.rmin, b.rmax, b.right };
-            };
-            open(todo[qi]);
-            while(ks.n < 4){
-                int best = -1; float ba = -1.0f;
-                for(int k = 0; k < ks.n; ++k) if(!(ks.k[k].code & kLeafFlag)){ float a = half_area(ks.k[k]); if(a > ba){ ba = a; best = k; } }
-                if(best < 0) break;
-                // an inner binary node has two children at most: opening one replaces it by them (n grows by one at most)
-                uint32_t c = ks.k[best].code;
-                ks.k[best] = ks.k[ks.n - 1]; --ks.n;
-                open(c);
-            }
-            for(int k = 0; k < 4; ++k){
-                if(k >= ks.n) ks.code[k] = kEmptyChild;
-                else if(ks.k[k].code & kLeafFlag) ks.code[k] = ks.k[k].code;
-                else { ks.code[k] = (uint32_t) todo.size(); todo.push_back(ks.k[k].code); depth.push_back(depth[qi] + 1); }
-            }
-            all.push_back(ks);
-            hs.wide_depth = std::max(hs.wide_depth, depth[qi]);
+        pod_vector<uint32_t> todo(hs.nodes.size() + 1);             // binary node each wide node was collapsed from (breadth-first)
+        pod_vector<Kids> all(hs.nodes.size() + 1);
+        todo[0] = 0u;
+        // pass 1, level by level: which child boxes a wide node holds; the inner ones among them are the next level (a chunk of
+        // the level counts its own, a prefix sum gives them their numbers)
+        size_t lvl_begin = 0, lvl_end = 1;
+        while(lvl_begin < lvl_end){
+            const size_t cnt = lvl_end - lvl_begin;
+            size_t per_chunk[kChunks] = {};
+            parallel_chunks(cnt, [&](int c, size_t b0, size_t e0){
+                size_t inner_kids = 0;
+                for(size_t i = b0; i < e0; ++i){
+                    Kids ks; ks.n = 0;
+                    auto open = [&](uint32_t idx){
+                        const BvhNode &b = hs.nodes[idx];
+                        if(b.left != kEmptyChild) ks.k[ks.n++] = Kid{ b.lmin, b.lmax, b.left };
+                        if(b.right != kEmptyChild) ks.k[ks.n++] = Kid{ b.rmin, b.rmax, b.right };
+                    };
+                    open(todo[lvl_begin + i]);
+                    while(ks.n < 4){
+                        int best = -1; float ba = -1.0f;
+                        for(int k = 0; k < ks.n; ++k) if(!(ks.k[k].code & kLeafFlag)){ float a = half_area(ks.k[k]); if(a > ba){ ba = a; best = k; } }
+                        if(best < 0) break;
+                        // an inner binary node has two children at most: opening one replaces it by them (n grows by one at most)
+                        uint32_t cc = ks.k[best].code;
+                        ks.k[best] = ks.k[ks.n - 1]; --ks.n;
+                        open(cc);
+                    }
+                    for(int k = 0; k < ks.n; ++k) if(!(ks.k[k].code & kLeafFlag)) ++inner_kids;
+                    all[lvl_begin + i] = ks;
+                }
+                per_chunk[c] = inner_kids;
+            });
+            size_t offs[kChunks], total = 0;
+            for(int c = 0; c < kChunks; ++c){ offs[c] = total; total += per_chunk[c]; }
+            parallel_chunks(cnt, [&](int c, size_t b0, size_t e0){
+                size_t o = lvl_end + offs[c];
+                for(size_t i = b0; i < e0; ++i){
+                    Kids &ks = all[lvl_begin + i];
+                    for(int k = 0; k < 4; ++k){
+                        if(k >= ks.n) ks.code[k] = kEmptyChild;
+                        else if(ks.k[k].code & kLeafFlag) ks.code[k] = ks.k[k].code;
+                        else { ks.code[k] = (uint32_t) o; todo[o++] = ks.k[k].code; }
+                    }
+                }
+            });
+            ++hs.wide_depth;
+            lvl_begin = lvl_end; lvl_end += total;
         }
+        all.resize(lvl_end);
         // pass 2: quantise and pack
-        hs.wnodes.assign(all.size(), WideNode{});
+        hs.wnodes.resize(all.size());
         parallel_chunks(all.size(), [&](int, size_t b0, size_t e0){
             for(size_t qi = b0; qi < e0; ++qi){
                 const Kids &ks = all[qi];
@@ -584,12 +656,14 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
 
     lap("wide");
     hs.tris.resize(nt);
-    {   // materials are numbered in order of first appearance (leaf order): one serial pass that mostly hits its one-entry cache
-        RefMat last; memset(&last, 0xFF, sizeof last); uint32_t last_idx = 0; bool have = false;
-        for(int s = 0; s < nt; ++s){
-            const RefMat &m = tris[B.prims[s].index].m;
+    // materials are numbered in order of first appearance in the INPUT (spheres, then triangles as handed over): one sequential
+    // pass over the records that mostly hits its one-entry cache; the leaf-order fill below looks the numbers up
+    pod_vector<uint32_t> mat_of((size_t) nt);
+    {   RefMat last; memset(&last, 0xFF, sizeof last); uint32_t last_idx = 0; bool have = false;
+        for(int i = 0; i < nt; ++i){
+            const RefMat &m = tris[i].m;
             if(!have || memcmp(&m, &last, 28) != 0){ last_idx = intern_material(m, mat_table, hs.materials); last = m; have = true; }
-            hs.tris[s].material = last_idx;
+            mat_of[(size_t) i] = last_idx;
         }
     }
     parallel_chunks((size_t) nt, [&](int, size_t b0, size_t e0){
@@ -602,6 +676,7 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
                 d.e2[a] = t.v2[a] - t.v0[a];
             }
             d.ordinal = (uint32_t) (ns + nl) + B.prims[s].index;
+            d.material = mat_of[B.prims[s].index];
             d.flags = (t.m.eta <= 0.0f) ? 1u : 0u;
         }
     });

@@ -45,7 +45,7 @@ int main(int argc, char **argv){
     HostScene hs;
     const char *err = build_host_scene(nullptr, 0, nullptr, 0, raw.data(), nt, hs);
     if(err && *err){ fprintf(stderr, "build: %s\n", err); return 1; }
-    const std::vector<BvhNode> &N = hs.nodes;
+    const auto &N = hs.nodes;
     // ---- collapse ----
     std::vector<Node4> N4; std::vector<int> map2to4(N.size(), -1);
     auto area = [](const float *mn, const float *mx){ float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2]; return dx * dy + dy * dz + dz * dx; };
