@@ -582,7 +582,11 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                                 HPT_SECTION(1, 3);                     // section d: one try of the unit-ball rejection loop
                                 float a = rng_next(rs), b = rng_next(rs), c = rng_next(rs);
                                 d_local = mk3(a, b, c) * 2.0f - mk3(1.0f, 1.0f, 1.0f);
+#ifdef HPT_KNOCK_BALL_TAIL       // development: upper bound of what any restructuring of the loop's tail could save (wrong image)
+                            } while(false);
+#else
                             } while(dot3(d_local, d_local) >= 1.0f);
+#endif
                             HPT_SECTION(2, 0);                         // section e: next-event geometry behind the loop
                             if(length3(d_local) > 0.001f) d_local = normalize3(d_local);
                             else d_local = mk3(0, 1, 0);
