@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <random>
 #include <vector>
 using namespace hpt;
@@ -80,7 +81,7 @@ int main(int argc, char **argv){
     std::mt19937 rng(7); std::uniform_real_distribution<float> U(0.0f, 1.0f);
     std::vector<double> cdf((size_t) hs.num_tris); double acc = 0;
     for(int i = 0; i < hs.num_tris; ++i){ const DevTriangle &t = hs.tris[(size_t) i]; V c = cross(V{t.e1[0], t.e1[1], t.e1[2]}, V{t.e2[0], t.e2[1], t.e2[2]}); acc += 0.5 * std::sqrt(dot(c, c)); cdf[(size_t) i] = acc; }
-    unsigned long long s2 = 0, s4 = 0, b2 = 0, b4 = 0, t2 = 0, t4 = 0, long2 = 0, long4 = 0, nlong = 0, max2 = 0, max4 = 0, s4u = 0, t4u = 0, long4u = 0, s4d = 0, t4d = 0, culled = 0;
+    unsigned long long s2 = 0, s4 = 0, b2 = 0, b4 = 0, t2 = 0, t4 = 0, long2 = 0, long4 = 0, nlong = 0, max2 = 0, max4 = 0, s4u = 0, t4u = 0, long4u = 0, s4d = 0, t4d = 0, culled = 0, c_long = 0, c_restart = 0, c_restart_t = 0, c_cont = 0, c_cont_t = 0, c_entries = 0, c_max_entries = 0;
     std::vector<uint32_t> stk(256);
     for(int r = 0; r < nr; ++r){
         double pick = U(rng) * acc; int ti = (int) (std::lower_bound(cdf.begin(), cdf.end(), pick) - cdf.begin()); ti = std::min(ti, hs.num_tris - 1);
@@ -144,6 +145,48 @@ int main(int argc, char **argv){
               cur = nd.c[idx[best]].code;
           } }
         if(steps > 6){ ++nlong; long2 += steps; long4 += steps4; long4u += steps4u; }
+        // the split trace step: six binary node steps (leaves tested as they come), then the four-wide walk (nearest child ordered)
+        // either RESTARTED at the root with the hit found so far as the limit (what k_trace does), or CONTINUED from the binary
+        // walk's own position: its current node and stack entries translated to four-wide codes (a binary node without a
+        // four-wide twin -- one that the collapse opened -- stands for its children, untested)
+        { float limit = 1e20f; int sp = 0; uint32_t cur = 0; unsigned long long st = 0, tt_ = 0; bool done = false;
+          for(;;){
+              if(cur & kLeafFlag){ leaf(cur, limit, tt_); if(sp == 0){ done = true; break; } cur = stk[(size_t) --sp]; continue; }
+              if(st >= 6) break;
+              ++st; const BvhNode &nd = N[cur]; float ln, rn;
+              bool hl = nd.left != kEmptyChild && slab(nd.lmin, nd.lmax, o, inv, limit, ln), hr = nd.right != kEmptyChild && slab(nd.rmin, nd.rmax, o, inv, limit, rn);
+              if(hl && hr){ bool lf = ln <= rn; stk[(size_t) sp++] = lf ? nd.right : nd.left; cur = lf ? nd.left : nd.right; }
+              else if(hl) cur = nd.left; else if(hr) cur = nd.right; else { if(sp == 0){ done = true; break; } cur = stk[(size_t) --sp]; }
+          }
+          if(!done){
+              ++c_long;
+              auto walk4 = [&](std::vector<uint32_t> &stack, float lim, unsigned long long &steps_out, unsigned long long &tris_out){
+                  uint32_t c = stack.back(); stack.pop_back();
+                  for(;;){
+                      if(c & kLeafFlag){ leaf(c, lim, tris_out); if(stack.empty()) break; c = stack.back(); stack.pop_back(); continue; }
+                      ++steps_out; const Node4 &nd = N4[c];
+                      float tn[4]; int idx[4], nh = 0, best = -1;
+                      for(int k = 0; k < nd.n; ++k){ float x; if(slab(nd.c[k].mn, nd.c[k].mx, o, inv, lim, x)){ tn[nh] = x; idx[nh] = k; if(best < 0 || x < tn[best]) best = nh; ++nh; } }
+                      if(nh == 0){ if(stack.empty()) break; c = stack.back(); stack.pop_back(); continue; }
+                      for(int i = 0; i < nh; ++i) if(i != best) stack.push_back(nd.c[idx[i]].code);
+                      c = nd.c[idx[best]].code;
+                  }
+              };
+              std::vector<uint32_t> a{0u}; walk4(a, limit, c_restart, c_restart_t);
+              // translate: bottom of the binary stack first, the current node on top
+              std::vector<uint32_t> b;
+              std::function<void(uint32_t)> put = [&](uint32_t code){
+                  if(code & kLeafFlag){ b.push_back(code); return; }
+                  if(map2to4[code] >= 0){ b.push_back((uint32_t) map2to4[code]); return; }
+                  const BvhNode &nd = N[code];
+                  if(nd.right != kEmptyChild) put(nd.right);
+                  if(nd.left != kEmptyChild) put(nd.left);
+              };
+              for(int i = 0; i < sp; ++i) put(stk[(size_t) i]);
+              put(cur);
+              c_entries += b.size(); c_max_entries = std::max<unsigned long long>(c_max_entries, b.size());
+              walk4(b, limit, c_cont, c_cont_t);
+          } }
     }
     printf("rays %d: binary %.2f node steps per ray (%.2f boxes, %.2f triangle tests, max %llu); 4-wide %.2f steps (%.2f boxes, %.2f triangle tests, max %llu)\n",
            nr, (double) s2 / nr, (double) b2 / nr, (double) t2 / nr, max2, (double) s4 / nr, (double) b4 / nr, (double) t4 / nr, max4);
@@ -153,5 +196,8 @@ int main(int argc, char **argv){
     printf("4-wide, nearest child ordered, distances kept on the stack: %.2f steps per ray (x %.3f), %.2f triangle tests (x %.3f), %.2f entries dropped per ray\n",
            (double) s4d / nr, (double) s4d / std::max(1ull, s4u), (double) t4d / nr, (double) t4d / std::max(1ull, t4u), (double) culled / nr);
     printf("rays with more than 6 binary steps: %.1f %%, binary %.2f steps, 4-wide %.2f (ratio %.3f)\n", 100.0 * nlong / nr, (double) long2 / std::max(1ull, nlong), (double) long4 / std::max(1ull, nlong), (double) long4 / std::max(1ull, long2));
+    printf("split step, %.1f %% of the rays set aside after 6 binary steps: four-wide RESTART %.2f steps and %.2f triangle tests per such ray; CONTINUED from the binary walk's position %.2f steps (x %.3f) and %.2f tests (x %.3f), %.2f translated entries per ray (max %llu)\n",
+           100.0 * c_long / nr, (double) c_restart / std::max(1ull, c_long), (double) c_restart_t / std::max(1ull, c_long), (double) c_cont / std::max(1ull, c_long), (double) c_cont / std::max(1ull, c_restart),
+           (double) c_cont_t / std::max(1ull, c_long), (double) c_cont_t / std::max(1ull, c_restart_t), (double) c_entries / std::max(1ull, c_long), c_max_entries);
     return 0;
 }
