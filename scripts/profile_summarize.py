@@ -1,5 +1,10 @@
 """Turns gpurun_out/<tag> (scripts/profile_round.sh) into the committed profiles/<tag>_* files."""
-import csv, glob, json, os, sys, collections, shutil
+import csv, glob as _glob, json, os, sys, collections, shutil
+
+class glob:                      # gpurun merges a call's files into what earlier calls left: always take the newest match
+    @staticmethod
+    def glob(pattern):
+        return sorted(_glob.glob(pattern), key=os.path.getmtime, reverse=True)[:1]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", tag)

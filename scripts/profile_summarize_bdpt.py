@@ -1,5 +1,10 @@
 """gpurun_out/<tag> (scripts/profile_bdpt.sh) -> profiles/<tag>_kernel_stats.csv + profiles/<tag>_pmc.json"""
-import csv, glob, json, os, re, shutil, sys, collections
+import csv, glob as _glob, json, os, re, shutil, sys, collections
+
+class glob:                      # gpurun merges a call's files into what earlier calls left: always take the newest match
+    @staticmethod
+    def glob(pattern):
+        return sorted(_glob.glob(pattern), key=os.path.getmtime, reverse=True)[:1]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02_bdpt"
