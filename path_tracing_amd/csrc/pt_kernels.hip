@@ -832,9 +832,12 @@ void k_tonemap(const float *linear, uint32_t *out_words, unsigned long long num_
 #else
 #define HPT_TRACE_ATTR
 #endif
-constexpr int kTraceChunk = 1024;     // rays per workgroup (with the branch-free node step: 512 -> 37.6 ms, 768 -> 36.5, 1024 -> 36.5, 1280 -> 36.1, 1536 -> 36.7, 2048 -> 38.4)
+constexpr int kTraceChunk = 2048;     // rays per workgroup of the first launch.  Round 1, unsplit step: 512 -> 37.6 ms, 768 -> 36.5, 1024 -> 36.5, 1280 -> 36.1,
+                                      // 1536 -> 36.7, 2048 -> 38.4.  Round 3, split step with the four-wide resume, two passes in flight (whose
+                                      // kernels fill each other's tails): 1024 -> 126.7 ms per 256-spp render of config 3, 1536 -> 125.8, 2048 -> 125.3,
+                                      // 3072 -> 126.1, 4096 -> 125.9; with refill at 56 idle lanes 2048 -> 124.5 (1 M triangles, 4096^2 x 8 spp: 74.2 -> 73.1)
 constexpr uint32_t kDoneCode = 0xFFFFFFFEu;   // leaf-flagged code a finished walk parks in cur
-constexpr int kRefillMin = 40;        // idle lanes that trigger a refill
+constexpr int kRefillMin = 56;        // idle lanes that trigger a refill (24 -> 34.4 ms per 64-spp pass, 32 -> 34.1, 40 -> 33.8, 48 -> 33.8, 56 -> 33.7)
 constexpr int kNodeMin = 4;           // fewer lanes than this still walking nodes (while others hold leaves): do the leaves first
                                       // (A/B: off 42.1 ms, 2: 39.9, 4: 39.4, 8: 40.2, 16: 41.3, 32: 43.2)
 constexpr uint32_t kTraceShortQueue = 1u << 20;   // below this many rays a workgroup takes 256 instead of kTraceChunk
