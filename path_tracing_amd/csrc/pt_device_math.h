@@ -16,6 +16,16 @@ namespace hpt {
 
 #define HPT_DEV __device__ __forceinline__
 
+// development (-DHPT_SHADE_PROFILE=3|4|5, counting renders only): wave trips and active lanes at probe points inside the BSDF
+// functions, counted through a pointer k_shade publishes (scripts/shade_sections.py); nothing in a product build
+#ifdef HPT_SHADE_PROFILE
+static __device__ unsigned long long *g_hpt_probe;
+#define HPT_PROBE(set, idx) do { unsigned long long *p_ = g_hpt_probe; if(p_ && HPT_SHADE_PROFILE == (set)){ unsigned long long m_ = __ballot(true); \
+    if((int) (threadIdx.x & 63u) == __ffsll((long long) m_) - 1){ atomicAdd(p_ + 2 * (idx), 1ull); atomicAdd(p_ + 2 * (idx) + 1, (unsigned long long) __popcll(m_)); } } } while(0)
+#else
+#define HPT_PROBE(set, idx) do {} while(0)
+#endif
+
 constexpr float kEps = 1e-4f;
 constexpr float kPi = 3.14159265358979323846f;
 
@@ -186,6 +196,7 @@ HPT_DEV void bsdf_eval_pdf_local(const Mat &m, f3 wo, f3 wi, f3 &f_out, float &p
     bool pdf_zero = !WANT_PDF || (wo.z * wi.z <= 0.0f);
     if(eval_zero && pdf_zero) return;
     if(m.eta > 0.0f && m.roughness < 0.001f) return;
+    HPT_PROBE(4, 0);                                               // past the early returns: a value and/or a pdf is wanted
     float alpha = roughness_to_alpha(m.roughness);
     f3 whv = wo + wi;
     if(length3(whv) < 1e-6f) return;
@@ -195,16 +206,18 @@ HPT_DEV void bsdf_eval_pdf_local(const Mat &m, f3 wo, f3 wi, f3 &f_out, float &p
     float lam_o = pre ? pre->lam_o : ggx_lambda(wo, alpha);
     float awo = fabsf(wo.z), awi = fabsf(wi.z);
     if(WANT_F && !eval_zero){
+        HPT_PROBE(4, 1);                                           // the value: G, Fresnel, specular term
         f3 diffuse = pre ? pre->diffuse : m.base / kPi * (1.0f - m.metallic);
         if(wo.z * wi.z < 0.0f) diffuse = mk3(0, 0, 0);
         float G = 1.0f / (1.0f + lam_o + ggx_lambda(wi, alpha));
         f3 F;
         if(m.metallic > 0.0f) F = fr_schlick(awo, m.base);
-        else { float fr = fr_dielectric(dot3(wo, wh), 1.0f, m.eta); F = mk3(fr, fr, fr); }
+        else { HPT_PROBE(4, 2); float fr = fr_dielectric(dot3(wo, wh), 1.0f, m.eta); F = mk3(fr, fr, fr); }
         f3 specular = (F * D * G) / fmaxf(4.0f * awo * awi, 1e-4f);
         f_out = (wo.z * wi.z > 0.0f) ? diffuse + specular : diffuse;
     }
     if(WANT_PDF && !pdf_zero){
+        HPT_PROBE(4, 3);                                           // the pdf
         float pdf_diffuse = awi / kPi;
         float G1 = 1.0f / (1.0f + lam_o);
         float pdf_wh = D * G1 * fmaxf(0.0f, dot3(wo, wh)) / awo;
@@ -230,6 +243,7 @@ HPT_DEV void bsdf_sample(const Mat &m, const ShadeCtx &c, float u_rr, float u1, 
     f3 wo = c.wo;
     f3 wi;
     if(m.eta > 0.0f && m.roughness < 0.001f && m.metallic < 0.01f){
+        HPT_PROBE(3, 0);                                           // smooth dielectric
         is_delta = true;
         float F = fr_dielectric(wo.z, cur_eta, m.eta);
         if(u_rr < F){
@@ -252,6 +266,7 @@ HPT_DEV void bsdf_sample(const Mat &m, const ShadeCtx &c, float u_rr, float u1, 
         return;
     }
     if(m.metallic > 0.99f && m.roughness < 0.001f){
+        HPT_PROBE(3, 1);                                           // mirror
         is_delta = true;
         wi = mk3(-wo.x, -wo.y, wo.z);
         pdf = 1.0f;
@@ -266,6 +281,7 @@ HPT_DEV void bsdf_sample(const Mat &m, const ShadeCtx &c, float u_rr, float u1, 
     float r = sqrtf(u1);
     float sn, cs; sincos_2pi(u2, sn, cs);
     if(u_rr < spec_weight){
+        HPT_PROBE(3, 2);                                           // specular lobe: visible-normal sample
         f3 wh = sample_visible_normal(wo.z > 0 ? wo : wo * -1.0f, alpha, r, sn, cs);
         if(wo.z < 0.0f) wh = wh * -1.0f;
         wi = reflect3(wo * -1.0f, wh);
@@ -274,6 +290,7 @@ HPT_DEV void bsdf_sample(const Mat &m, const ShadeCtx &c, float u_rr, float u1, 
         wi = mk3(r * cs, r * sn, sqrtf(fmaxf(0.0f, 1.0f - u1)));
         if(wo.z < 0.0f) wi.z *= -1.0f;
     }
+    HPT_PROBE(3, 3);                                               // both lobes: value and pdf of the sampled direction
     wi_w = to_world(wi, c.T, c.B, c.N);
     bsdf_eval_pdf(m, c, wi_w, f, pdf, pre);
 }

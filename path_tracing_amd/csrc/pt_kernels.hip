@@ -338,7 +338,7 @@ constexpr int kNeeWords = 20;
 // 0-2 wo (local) | 3-5 wi (local) | 6 Lambda(wo) | 7 material index | 8-10 throughput | 11 pdf_light_dir |
 // 12-14 shadow segment start | 15-17 shadow segment end | 18 path slot | 19 light index | parallel << 31
 
-// development (-DHPT_SHADE_PROFILE=1|2, counting renders only): how many wave trips enter a section of k_shade and with how many
+// development (-DHPT_SHADE_PROFILE=1|2|5, counting renders only; 3 and 4: probes inside the BSDF functions, pt_device_math.h): how many wave trips enter a section of k_shade and with how many
 // lanes, through the eight bd_* counters (four sections per build): scripts/shade_sections.py
 #ifdef HPT_SHADE_PROFILE
 #define HPT_SECTION(set, idx) do { if(wc && HPT_SHADE_PROFILE == (set)){ unsigned long long m_ = __ballot(true); \
@@ -401,6 +401,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                 contrib = thr * brdf * illum * mk3(1.0f, 1.0f, 1.0f) * cos_surface / pdf_light_dir * mis_w;
             }
             if(is_valid_color(contrib)){
+                HPT_SECTION(5, 3);                                     // next-event contribution kept: shadow record written
                 want = true;
                 f3 c = clamp_radiance(contrib, 15.0f);
                 f3 diff = p2 - p1;                              // geometric.cuh:298-303
@@ -414,6 +415,9 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
         uint32_t spos = lds_push(want, &s_cnt[1]);
         if(want) s_shadow[spos] = spath;
     };
+#ifdef HPT_SHADE_PROFILE
+    g_hpt_probe = wc ? &wc->bd_pairs : nullptr;            // every thread stores the same value before it reads it
+#endif
     if(threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
     const bool mats_in_lds = sc.num_mats <= kLdsMats;
     const bool lights_in_lds = sc.num_lights <= kLdsLights;
@@ -625,6 +629,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                         HPT_SECTION(2, 2);                             // section g: throughput update and continuation
                         f3 new_o;
                         if(is_delta){
+                            HPT_SECTION(5, 0);                         // delta continuation
                             throughput = throughput * bsdf_val;
                             ray_eta = new_eta;
                             if(dot3(wi, normal) < 0.0f) new_o = pos - normal * kEps;
@@ -633,6 +638,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                             ++delta_count;
                             alive = is_valid_color(throughput) && delta_count <= max_delta;
                         } else {
+                            HPT_SECTION(5, 1);                         // non-delta continuation
                             float cos_wi = fabsf(dot3(normal, wi));
                             throughput = throughput * bsdf_val * cos_wi / pdf_omega;
                             new_o = pos + normal * kEps;
@@ -648,6 +654,7 @@ void k_shade(SceneDev sc, PathBuf pb, const uint32_t *queue, const uint32_t *qco
                             alive = alive && depth < max_depth;
                         }
                         if(alive){
+                            HPT_SECTION(5, 2);                         // the path goes on: state written back
                             uint32_t nf = (last_is_delta ? 1u : 0u) | ((uint32_t) depth << 8) | ((uint32_t) delta_count << 16);
                             pb.org_eta[path] = make_float4(new_o.x, new_o.y, new_o.z, ray_eta);
                             pb.dir_flags[path] = make_float4(wi.x, wi.y, wi.z, u2f(nf));
