@@ -262,8 +262,10 @@ void hpt_tonemap_reference(const float *linear_rgb, unsigned char *rgb8, int64_t
  * kernels walk is this library's own, and the work counts the bench's roofline is built from (hpt_stats.boxes_*,
  * tris_*) are counts of walking it.  These two calls hand the tree out so that an independent walker -- the oracle's
  * host traversal, oracle/pt_oracle.cpp -- can reproduce those counts ray by ray.
- *   qnodes_out  num_nodes records of 32 B: child boxes lmin, lmax, rmin, rmax as 3 x uint16 grid coordinates each
- *               (coordinate = qorigin + q * qscale), then the two uint32 child codes: bit 31 set = leaf,
+ *   qnodes_out  num_nodes records of 32 B: six words of uint16 grid coordinates (coordinate = qorigin + q * qscale) --
+ *               per axis x, y, z one word with the lower plane of the left child's box in its low half and of the right
+ *               child's in its high half, then one word with the two upper planes the same way -- then the two uint32
+ *               child codes: bit 31 set = leaf,
  *               (code & 0x7FFFFFFF) >> 3 = first triangle slot, (code & 7) + 1 = triangle count; 0xFFFFFFFF = no
  *               child; otherwise the index of an inner node.  Node 0 is the root.
  *   tris_out    num_tris records of 48 B in leaf order: v0 | scan ordinal, v1 - v0 | material, v2 - v0 | flags

@@ -101,14 +101,15 @@ struct WalkRay {
 // one inner-node step: returns the next code and updates the stack
 static inline uint32_t node_step(const OracleBvh &b, const WalkRay &r, uint32_t cur, float limit, uint32_t *stk, int &sp){
     const uint32_t *w = b.qnodes + (size_t) cur * 8;
-    float a0 = fmaf((float) (w[0] & 0xFFFFu), r.ix, r.ox), a1 = fmaf((float) (w[1] >> 16), r.ix, r.ox);
-    float b0 = fmaf((float) (w[0] >> 16), r.iy, r.oy), b1 = fmaf((float) (w[2] & 0xFFFFu), r.iy, r.oy);
-    float c0 = fmaf((float) (w[1] & 0xFFFFu), r.iz, r.oz), c1 = fmaf((float) (w[2] >> 16), r.iz, r.oz);
+    // words 0-5: per axis the lower planes of (left | right << 16), then the upper planes (include/hpt.h, hpt_bvh_export_host)
+    float a0 = fmaf((float) (w[0] & 0xFFFFu), r.ix, r.ox), a1 = fmaf((float) (w[1] & 0xFFFFu), r.ix, r.ox);
+    float b0 = fmaf((float) (w[2] & 0xFFFFu), r.iy, r.oy), b1 = fmaf((float) (w[3] & 0xFFFFu), r.iy, r.oy);
+    float c0 = fmaf((float) (w[4] & 0xFFFFu), r.iz, r.oz), c1 = fmaf((float) (w[5] & 0xFFFFu), r.iz, r.oz);
     float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
     float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
-    a0 = fmaf((float) (w[3] & 0xFFFFu), r.ix, r.ox); a1 = fmaf((float) (w[4] >> 16), r.ix, r.ox);
-    b0 = fmaf((float) (w[3] >> 16), r.iy, r.oy); b1 = fmaf((float) (w[5] & 0xFFFFu), r.iy, r.oy);
-    c0 = fmaf((float) (w[4] & 0xFFFFu), r.iz, r.oz); c1 = fmaf((float) (w[5] >> 16), r.iz, r.oz);
+    a0 = fmaf((float) (w[0] >> 16), r.ix, r.ox); a1 = fmaf((float) (w[1] >> 16), r.ix, r.ox);
+    b0 = fmaf((float) (w[2] >> 16), r.iy, r.oy); b1 = fmaf((float) (w[3] >> 16), r.iy, r.oy);
+    c0 = fmaf((float) (w[4] >> 16), r.iz, r.oz); c1 = fmaf((float) (w[5] >> 16), r.iz, r.oz);
     float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
     float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
     uint32_t lc = w[6], rc = w[7];

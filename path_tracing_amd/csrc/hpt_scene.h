@@ -46,8 +46,11 @@ struct BvhNode {           // 64 B
 // Quantised twin of BvhNode, 32 B: child boxes as 16-bit grid coordinates of the scene box
 // (min rounded down, max rounded up, so the quantised box contains the float box); two dwordx4
 // fetches per node visit instead of four.  Traversal only needs conservative boxes.
+// plane[axis][0 = lower, 1 = upper][0 = left child, 1 = right child]: word 2 * axis holds the lower planes of both children, word
+// 2 * axis + 1 the upper ones -- t = q * i + o is monotone in q, so a ray takes its near planes from one word and its far planes
+// from the other by the sign of its direction (one bit-select per word, no min / max per plane pair)
 struct QBvhNode {
-    uint16_t lmin[3], lmax[3], rmin[3], rmax[3];
+    uint16_t plane[3][2][2];
     uint32_t left, right;
 };
 

@@ -863,7 +863,7 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
     int sp = 0;
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
     float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
-    uint32_t mx = 0u, my = 0u, mz = 0u;          // WIDE: all ones where the ray runs against the axis (its near plane is a box's upper one)
+    uint32_t mx = 0u, my = 0u, mz = 0u;          // all ones where the ray runs against the axis (its near plane is a box's upper one)
     float tmax = 0.0f, limit = 0.0f, best_t = 1e20f;
     uint32_t best_prim = kHitMiss, best_ord = 0xFFFFFFFFu;
     unsigned long long n_lane_steps = 0, n_wave_steps = 0, n_boxes = 0, n_tris = 0, n_rays = 0, n_leaf_lane = 0, n_leaf_wave = 0;
@@ -963,7 +963,7 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
                         // quantised boxes: plane = qorigin + q * qscale, so t = q * (qscale * inv) + (qorigin - o) * inv
                         ox = (sc.qorigin[0] - ro.x) * ix; oy = (sc.qorigin[1] - ro.y) * iy; oz = (sc.qorigin[2] - ro.z) * iz;
                         ix *= sc.qscale[0]; iy *= sc.qscale[1]; iz *= sc.qscale[2];
-                        if(WIDE){ mx = ix < 0.0f ? 0xFFFFFFFFu : 0u; my = iy < 0.0f ? 0xFFFFFFFFu : 0u; mz = iz < 0.0f ? 0xFFFFFFFFu : 0u; }
+                        mx = ix < 0.0f ? 0xFFFFFFFFu : 0u; my = iy < 0.0f ? 0xFFFFFFFFu : 0u; mz = iz < 0.0f ? 0xFFFFFFFFu : 0u;
                         cur = 0u; sp = 0; steps = 0u;
                         active = true;
                     }
@@ -1046,17 +1046,16 @@ HPT_DEV void trace_chunk(const SceneDev &sc, PathBuf pb, ShadowBuf sb, const uin
             // breadth-first node order puts among the first kTopNodes: those sit in LDS (staged once per workgroup)
             const uint4 *n = TOP ? top + cur * 2u : sc.qnodes + (size_t) cur * 2;
             uint4 w0 = n[0], w1 = n[1];
-            // lmin.xyz lmax.xyz rmin.xyz rmax.xyz as 16-bit grid coordinates, then the two child codes
-            float a0 = fmaf((float) (w0.x & 0xFFFFu), ix, ox), a1 = fmaf((float) (w0.y >> 16), ix, ox);
-            float b0 = fmaf((float) (w0.x >> 16), iy, oy), b1 = fmaf((float) (w0.z & 0xFFFFu), iy, oy);
-            float c0 = fmaf((float) (w0.y & 0xFFFFu), iz, oz), c1 = fmaf((float) (w0.z >> 16), iz, oz);
-            float ln = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-            float lf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
-            a0 = fmaf((float) (w0.w & 0xFFFFu), ix, ox); a1 = fmaf((float) (w1.x >> 16), ix, ox);
-            b0 = fmaf((float) (w0.w >> 16), iy, oy); b1 = fmaf((float) (w1.y & 0xFFFFu), iy, oy);
-            c0 = fmaf((float) (w1.x & 0xFFFFu), iz, oz); c1 = fmaf((float) (w1.y >> 16), iz, oz);
-            float rn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-            float rf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), limit));
+            // per axis one word of lower planes (left | right << 16) and one of upper planes, then the two child codes.  t = q * i + o
+            // is monotone in q: the near plane of an axis is the lower one when i >= 0 and the upper one otherwise, so one
+            // bit-select per word picks the near (far) planes of both children -- the same values min / max of the pair give
+            const uint32_t nx = bit_select(mx, w0.y, w0.x), fx = bit_select(mx, w0.x, w0.y);
+            const uint32_t ny = bit_select(my, w0.w, w0.z), fy = bit_select(my, w0.z, w0.w);
+            const uint32_t nz = bit_select(mz, w1.y, w1.x), fz = bit_select(mz, w1.x, w1.y);
+            float ln = fmaxf(fmaxf(fmaf(lo16f(nx), ix, ox), fmaf(lo16f(ny), iy, oy)), fmaxf(fmaf(lo16f(nz), iz, oz), 0.0f));
+            float lf = fminf(fminf(fmaf(lo16f(fx), ix, ox), fmaf(lo16f(fy), iy, oy)), fminf(fmaf(lo16f(fz), iz, oz), limit));
+            float rn = fmaxf(fmaxf(fmaf(hi16f(nx), ix, ox), fmaf(hi16f(ny), iy, oy)), fmaxf(fmaf(hi16f(nz), iz, oz), 0.0f));
+            float rf = fminf(fminf(fmaf(hi16f(fx), ix, ox), fmaf(hi16f(fy), iy, oy)), fminf(fmaf(hi16f(fz), iz, oz), limit));
             uint32_t lc = w1.z, rc = w1.w;
             bool hl = (ln <= lf * 1.000002f) && (lc != kEmptyChild);
             bool hr = (rn <= rf * 1.000002f) && (rc != kEmptyChild);

@@ -568,8 +568,8 @@ const char *build_host_scene(const void *lights_v, int nl, const void *spheres_v
             for(size_t i = b0; i < e0; ++i){
                 const BvhNode &n = hs.nodes[i]; QBvhNode &q = hs.qnodes[i];
                 for(int a = 0; a < 3; ++a){
-                    if(n.left != kEmptyChild){ q.lmin[a] = qlo(n.lmin[a], a); q.lmax[a] = qhi(n.lmax[a], a); } else { q.lmin[a] = 65535; q.lmax[a] = 0; }
-                    if(n.right != kEmptyChild){ q.rmin[a] = qlo(n.rmin[a], a); q.rmax[a] = qhi(n.rmax[a], a); } else { q.rmin[a] = 65535; q.rmax[a] = 0; }
+                    if(n.left != kEmptyChild){ q.plane[a][0][0] = qlo(n.lmin[a], a); q.plane[a][1][0] = qhi(n.lmax[a], a); } else { q.plane[a][0][0] = 65535; q.plane[a][1][0] = 0; }
+                    if(n.right != kEmptyChild){ q.plane[a][0][1] = qlo(n.rmin[a], a); q.plane[a][1][1] = qhi(n.rmax[a], a); } else { q.plane[a][0][1] = 65535; q.plane[a][1][1] = 0; }
                 }
                 q.left = n.left; q.right = n.right;
             }
