@@ -74,9 +74,15 @@ constexpr uint32_t kResumeMaxGroups = 8192;   // grid cap of the resume launch
 constexpr int kDeepLevels = 48;      // global-memory stack levels per lane of the resume launch (the four-wide walk stacks up to three children per step)
 constexpr int kWideRefillMin = 24;   // the same two thresholds for the four-wide resume launch (A/B grid 16/24/32 x 12/16/24 on configs 3 and 5)
 constexpr int kWideNodeMin = 16;
-constexpr int kTraceBudget = 6;      // node steps a ray gets in the first trace launch before it is set aside
-constexpr int kTopLevels = 6;        // a budget of at most this many steps keeps a ray among the first kTopNodes nodes
-constexpr int kTopNodes = 64;        // (breadth-first order, scene_build.cpp): 2^kTopLevels - 1 = 63 nodes of 32 B, staged in LDS
+#ifndef HPT_TRACE_BUDGET             // development A/B: `make variant EXTRA="-DHPT_TRACE_BUDGET=7 -DHPT_TOP_LEVELS=7"`
+#define HPT_TRACE_BUDGET 6
+#endif
+#ifndef HPT_TOP_LEVELS
+#define HPT_TOP_LEVELS 6
+#endif
+constexpr int kTraceBudget = HPT_TRACE_BUDGET;   // node steps a ray gets in the first trace launch before it is set aside
+constexpr int kTopLevels = HPT_TOP_LEVELS;       // a budget of at most this many steps keeps a ray among the first kTopNodes nodes
+constexpr int kTopNodes = 1 << kTopLevels;       // (breadth-first order, scene_build.cpp): 2^kTopLevels - 1 = 63 nodes of 32 B, staged in LDS
 
 void launch_generate(hipStream_t s, const Tiling &tl, const CameraDev &cam, PathBuf pb,
                      uint32_t *qcount, int samples_this_pass, uint32_t first_sample, uint64_t seed,
