@@ -1396,7 +1396,7 @@ void launch_trace_resume(hipStream_t s, const SceneDev &sc, PathBuf pb, ShadowBu
     uint32_t chunk2 = kLongChunk; int refill2 = kLongRefillMin, node_min2 = kLongNodeMin;
     {   // development sweeps (hpt_params.flags bits 21-28): refill threshold, early-leaf-break threshold, chunk
         static const int refill_tab[8] = { 0, 8, 16, 24, 32, 40, 48, 56 }, node_tab[8] = { 0, 1, 2, 4, 12, 16, 24, 32 };
-        static const uint32_t chunk_tab[4] = { 0u, 1024u, 4096u, 512u };
+        static const uint32_t chunk_tab[4] = { 0u, 1024u, 2048u, 512u };
         if(dev_tuning & 7) refill2 = refill_tab[dev_tuning & 7];
         if((dev_tuning >> 3) & 7) node_min2 = node_tab[(dev_tuning >> 3) & 7];
         if((dev_tuning >> 6) & 3) chunk2 = chunk_tab[(dev_tuning >> 6) & 3];
